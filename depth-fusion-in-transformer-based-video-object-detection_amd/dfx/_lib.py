@@ -1,0 +1,53 @@
+"""ctypes loader of libdfx.so (the C ABI declared in include/dfx_msda.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdfx.so")
+_lib = None
+
+_i, _l, _p = ctypes.c_int, ctypes.c_long, ctypes.c_void_p
+_DIMS = [_i] * 7  # N, S, M, D, L, Lq, P
+
+# name -> argtypes; every function returns int (0 = ok, <0 = DFX_E*)
+SIGNATURES = {
+    "dfx_msda_forward_f32": [_p] * 5 + _DIMS + [_p, _p],
+    "dfx_msda_forward_f64": [_p] * 5 + _DIMS + [_p, _p],
+    "dfx_msda_backward_f32": [_p] * 6 + _DIMS + [_p, _p, _p, _p],
+    "dfx_msda_backward_f64": [_p] * 6 + _DIMS + [_p, _p, _p, _p],
+    "dfx_msda_fused_forward_f32": [_p, _p, _p, _p, _i, _i, _p, _l, _p, _l] + _DIMS + [_p, _p],
+}
+
+
+def library_path():
+    return _SO
+
+
+def load():
+    """Return the loaded library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                f"{_SO} is missing: the HIP extension has not been built "
+                "(run `python __graft_entry__.py build` or `make -C <pkg>/csrc`). "
+                "There is no CPU or PyTorch fallback for this operator.")
+        lib = ctypes.CDLL(_SO)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.dfx_abi_version.restype = ctypes.c_int
+        lib.dfx_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def abi_version():
+    return load().dfx_abi_version()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dfx_last_error().decode() or f"error code {rc}"
+        raise RuntimeError(f"{what}: {msg}")

@@ -1,0 +1,130 @@
+"""torch-tensor front ends of the C ABI (device pointers + torch's current stream).
+
+Mirrors the host half of the reference's CUDA op
+(/root/reference/models/ops/src/cuda/ms_deform_attn_cuda.cu:20-153): the same
+argument checks, the same dimension derivation (L from spatial_shapes.size(0), Lq from
+sampling_loc.size(1), P from sampling_loc.size(4)), fresh output tensors.
+"""
+import torch
+
+from . import _lib
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_inputs(named):
+    for name, t in named:
+        _require(t.is_contiguous(), f"{name} tensor has to be contiguous")
+    for name, t in named:
+        # the reference raises "Not implemented on the CPU" (ms_deform_attn.h:38,60)
+        _require(t.is_cuda, f"{name} must be a CUDA tensor (MSDA is not implemented on the CPU)")
+    dev = named[0][1].device
+    for name, t in named:
+        _require(t.device == dev, f"{name} is on {t.device}, expected {dev}")
+
+
+def _dims(value, spatial_shapes, sampling_loc, im2col_step):
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq = sampling_loc.shape[1]
+    P = sampling_loc.shape[4]
+    step = min(N, im2col_step)
+    _require(step > 0 and N % step == 0, f"batch({N}) must divide im2col_step({step})")
+    return N, S, M, D, L, Lq, P
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    lib = _lib.load()
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    _require(value.dtype in _SUFFIX, f"ms_deform_attn_forward not implemented for {value.dtype}")
+    _require(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype,
+             "value, sampling_loc and attn_weight must share one dtype")
+    _require(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
+             "spatial_shapes and level_start_index must be int64")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    _require(sampling_loc.numel() >= N * Lq * M * L * P * 2 and attn_weight.numel() >= N * Lq * M * L * P,
+             "sampling_loc / attn_weight smaller than N*Lq*M*L*P")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    fn = getattr(lib, "dfx_msda_forward_" + _SUFFIX[value.dtype])
+    with torch.cuda.device(value.device):
+        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
+                out.data_ptr(), _stream(value.device))
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                  im2col_step=64):
+    lib = _lib.load()
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    _require(value.dtype in _SUFFIX, f"ms_deform_attn_backward not implemented for {value.dtype}")
+    _require(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype
+             and grad_output.dtype == value.dtype, "all floating inputs must share one dtype")
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    _require(grad_output.numel() == N * Lq * M * D, "grad_output has the wrong size")
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.zeros_like(sampling_loc)
+    grad_aw = torch.zeros_like(attn_weight)
+    fn = getattr(lib, "dfx_msda_backward_" + _SUFFIX[value.dtype])
+    with torch.cuda.device(value.device):
+        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr(),
+                _stream(value.device))
+    _lib.check(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_aw]
+
+
+def fused_supported(value, M, D, L, P, Lr):
+    """Geometry the fused front-end kernel covers (else callers take the unfused op)."""
+    return (value.is_cuda and value.dtype == torch.float32 and M == 8 and D == 32 and P == 4
+            and 1 <= L <= 4 and (Lr == L or L == 1))
+
+
+def msda_fused_forward(value, spatial_shapes, level_start_index, reference_points, qproj, n_levels, n_points):
+    """softmax + location arithmetic + sampling in one launch (include/dfx_msda.h,
+    dfx_msda_fused_forward_f32).
+
+    value            [N,S,M,D] fp32, contiguous
+    reference_points [N,Lq,Lr,2|4]
+    qproj            [N,Lq,3*M*L*P] = one row per query holding the raw sampling_offsets
+                     Linear output (M*L*P*2 floats) followed by the raw attention_weights
+                     Linear output (M*L*P floats)
+    -> [N,Lq,M*D]
+    """
+    lib = _lib.load()
+    reference_points = reference_points.contiguous()
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("reference_points", reference_points),
+                   ("qproj", qproj)])
+    N, S, M, D = value.shape
+    L, P = n_levels, n_points
+    _require(spatial_shapes.shape[0] == L, "spatial_shapes rows must equal n_levels")
+    Lq, Lr, ref_dim = reference_points.shape[1], reference_points.shape[2], reference_points.shape[3]
+    mlp = M * L * P
+    _require(qproj.shape == (N, Lq, 3 * mlp) and qproj.dtype == torch.float32, "qproj has the wrong shape/dtype")
+    _require(reference_points.dtype == torch.float32 and reference_points.shape[0] == N, "bad reference_points")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    base = qproj.data_ptr()
+    with torch.cuda.device(value.device):
+        rc = lib.dfx_msda_fused_forward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            reference_points.data_ptr(), ref_dim, Lr,
+            base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
+            N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
+    _lib.check(rc, "msda_fused_forward")
+    return out

@@ -1,0 +1,121 @@
+"""``MSDeformAttn``: the multi-scale deformable attention module, reference surface
+(/root/reference/models/ops/modules/ms_deform_attn.py:30-117) on the gfx950 kernels.
+
+Same constructor, parameter names (``sampling_offsets``, ``attention_weights``,
+``value_proj``, ``output_proj`` -> same state_dict keys), initialisation and forward
+signature as the reference.  Two execution routes:
+
+* inference on the GPU with the production head geometry (8 heads x 32 channels, 4 points,
+  <= 4 levels, fp32): ONE GEMM produces [offsets | logits] per query and the fused kernel
+  (csrc/msda_fused.hip) does softmax, location arithmetic and sampling in one launch;
+* anything else (training, fp64, odd geometry): the reference's op sequence with the
+  autograd operator ``MSDeformAttnFunction`` (csrc/msda_forward.hip / msda_backward.hip).
+
+There is no CPU route: like the reference's op (ms_deform_attn.h:38) it raises on CPU tensors.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from dfx import ops as _ops
+from ..functions import ms_deform_attn_func as _func
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a power-of-2 head dimension maps best onto the kernels "
+                          "(32 channels per head takes the wave-per-query fast path).")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        mlp = n_heads * n_levels * n_points
+        self.sampling_offsets = nn.Linear(d_model, mlp * 2)
+        self.attention_weights = nn.Linear(d_model, mlp)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._qproj_cache = None
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """ref :62-76 - zero offset weights, ring-shaped offset bias (head h points along angle
+        2*pi*h/n_heads, point i at radius i+1), zero attention logits, xavier projections."""
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+            ring = torch.stack([angle.cos(), angle.sin()], -1)
+            ring = ring / ring.abs().max(-1, keepdim=True)[0]
+            ring = ring.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+            ring = ring * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+            self.sampling_offsets.bias = nn.Parameter(ring.reshape(-1))
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    # -- one GEMM for both query projections (weights concatenated lazily, refreshed when edited) --
+    def _qproj_params(self):
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version,
+               so.weight.data_ptr(), aw.weight.data_ptr(), so.weight.device, so.weight.dtype)
+        if self._qproj_cache is None or self._qproj_cache[0] != key:
+            w = torch.cat([so.weight.detach(), aw.weight.detach()], 0).contiguous()
+            b = torch.cat([so.bias.detach(), aw.bias.detach()], 0).contiguous()
+            self._qproj_cache = (key, w, b)
+        return self._qproj_cache[1], self._qproj_cache[2]
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """query [N,Lq,C]; reference_points [N,Lq,L,2] (or 4: cx,cy,w,h) in [0,1];
+        input_flatten [N,sum(H_l*W_l),C]; input_spatial_shapes i64 [L,2]; input_level_start_index
+        i64 [L]; input_padding_mask [N,S] True = padding.  -> [N,Lq,C]   (ref :78-117)"""
+        N, Lq, _ = query.shape
+        _, S, _ = input_flatten.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        D = self.d_model // M
+        if getattr(input_spatial_shapes, "_dfx_tokens", None) != S:
+            # one device read per distinct shapes tensor (the reference asserts on every call, ref :92)
+            assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
+            input_spatial_shapes._dfx_tokens = S
+        ref_dim = reference_points.shape[-1]
+        if ref_dim not in (2, 4):
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref_dim} instead.")
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, S, M, D)
+
+        fused = (not torch.is_grad_enabled() or not (query.requires_grad or value.requires_grad)) \
+            and _ops.fused_supported(value, M, D, L, P, reference_points.shape[2]) and value.is_contiguous()
+        if fused:
+            w, b = self._qproj_params()
+            qproj = F.linear(query, w, b)
+            sampled = _ops.msda_fused_forward(value, input_spatial_shapes, input_level_start_index,
+                                              reference_points, qproj, L, P)
+            return self.output_proj(sampled)
+
+        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
+        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        if ref_dim == 2:
+            wh = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+        else:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        sampled = _func.MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                   locations.contiguous(), weights, self.im2col_step)
+        return self.output_proj(sampled)

@@ -1,0 +1,109 @@
+/*
+ * dfx_msda.h -- C ABI of the MI355X (gfx950) multi-scale deformable attention path.
+ *
+ * This is the drop-in boundary: the entry points are exactly what a binding for
+ * the reference's only native component would call.  The reference exposes that
+ * component as the pybind11 module `MultiScaleDeformableAttention` with
+ *   ms_deform_attn_forward   /root/reference/models/ops/src/ms_deform_attn.h:20-38
+ *   ms_deform_attn_backward  /root/reference/models/ops/src/ms_deform_attn.h:41-61
+ * (bound in models/ops/src/vision.cpp:13-16, implemented for CUDA in
+ *  models/ops/src/cuda/ms_deform_attn_cuda.cu:20-153).  The Python shim that
+ * turns these C calls back into that module lives in
+ *   depth-fusion-in-transformer-based-video-object-detection_amd/MultiScaleDeformableAttention.py
+ * and INTEGRATION.md shows the few lines a maintainer of the reference adds.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; no torch / ATen types cross this boundary;
+ *   - every pointer is DEVICE memory (HBM) of the current HIP device, including
+ *     `shapes` and `lsi` (the reference keeps them on the device as int64);
+ *   - buffers are packed, row-major, and addressed FLAT with strides derived
+ *     from the integer arguments (ms_deform_attn_cuda.cu:40-48,58-60): a
+ *     sampling-location buffer that is larger than N*Lq*M*L*P*2 is legal and
+ *     only its prefix is read (the TransVOD temporal decoder relies on this);
+ *   - the call only ENQUEUES work on `stream` (a hipStream_t; NULL = the
+ *     default stream) and returns; no allocation, no synchronisation, no global
+ *     state, re-entrant;
+ *   - the caller owns every buffer; outputs are fully overwritten by forward;
+ *     backward ACCUMULATES into grad_value and overwrites the flat prefix of
+ *     grad_loc / grad_aw, so the caller zero-fills all three first (the
+ *     reference allocates them with zeros_like, ms_deform_attn_cuda.cu:116-118);
+ *   - return value: 0 on success, a negative DFX_E* code otherwise; no C++
+ *     exception ever crosses the boundary; dfx_last_error() gives the text.
+ */
+#ifndef DFX_MSDA_H
+#define DFX_MSDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFX_OK 0
+#define DFX_EINVAL (-1)  /* bad dimension / null pointer                         */
+#define DFX_ELAUNCH (-2) /* hipGetLastError() reported a launch failure          */
+#define DFX_ERANGE (-3)  /* sizes overflow the 32-bit index space of the kernels */
+
+/* ABI version: bumped whenever a signature below changes. */
+int dfx_abi_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *dfx_last_error(void);
+
+/*
+ * Forward: out[b,q,m,c] = sum_{l,p} aw[b,q,m,l,p] * bilinear(value_l[b,:,m,c], x*W_l-0.5, y*H_l-0.5)
+ * Replaces ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:20-80) and the
+ * kernel ms_deformable_im2col_gpu_kernel (ms_deform_im2col_cuda.cuh:237-299).
+ *   value  [N,S,M,D]        shapes int64 [L,2] = (H_l, W_l)      lsi int64 [L]
+ *   loc    >= N*Lq*M*L*P*2  aw >= N*Lq*M*L*P                     out [N,Lq,M*D]
+ */
+int dfx_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *aw,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         float *out, void *stream);
+int dfx_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                         const double *loc, const double *aw,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         double *out, void *stream);
+
+/*
+ * Backward.  Replaces ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:83-153)
+ * and the six col2im kernel variants (ms_deform_im2col_cuda.cuh:301-920).
+ *   grad_out [N,Lq,M*D]; grad_value like value; grad_loc like loc; grad_aw like aw.
+ */
+int dfx_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *aw, const float *grad_out,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          float *grad_value, float *grad_loc, float *grad_aw, void *stream);
+int dfx_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                          const double *loc, const double *aw, const double *grad_out,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          double *grad_value, double *grad_loc, double *grad_aw, void *stream);
+
+/*
+ * Fused front end + sampling (inference): what MSDeformAttn.forward does between
+ * its Linear layers (/root/reference/models/ops/modules/ms_deform_attn.py:98-114):
+ *   aw  = softmax over (L*P) of logits[b,q,m,:]
+ *   loc = ref[b,q,l,:2] + off[b,q,m,l,p,:] / (W_l,H_l)                (ref_dim == 2)
+ *   loc = ref[b,q,l,:2] + off[b,q,m,l,p,:] / P * ref[b,q,l,2:] * 0.5  (ref_dim == 4)
+ * followed by the forward above, without materialising loc / aw in HBM.
+ *   off    [N,Lq,M,L,P,2] raw sampling_offsets Linear output, row stride
+ *          `off_stride` floats between consecutive (b,q) rows (>= M*L*P*2)
+ *   logits [N,Lq,M,L*P]   raw attention_weights Linear output, row stride
+ *          `logit_stride` floats (>= M*L*P); both strides let one GEMM write a
+ *          concatenated [offsets | logits] row
+ *   ref    [N,Lq,Lr,ref_dim]; Lr == L normally.  Lr > L reproduces the flat
+ *          read of the TransVOD temporal decoder: the
+ *          virtual location tensor is [N,Lq,M,Lr,P,2] read flat with L levels.
+ */
+int dfx_msda_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                               const float *ref, int ref_dim, int Lr,
+                               const float *off, long off_stride,
+                               const float *logits, long logit_stride,
+                               int N, int S, int M, int D, int L, int Lq, int P,
+                               float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_MSDA_H */

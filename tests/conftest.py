@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import msda_oracle
+    msda_oracle.build()
+    return msda_oracle
+
+
+@pytest.fixture()
+def cpu_msda(oracle, monkeypatch):
+    """Route the product's autograd op through the CPU oracle so host logic (modules, layers,
+    detectors) can be exercised without a GPU.  Test-only: product code has no such switch."""
+    import models.ops.functions.ms_deform_attn_func as f
+    monkeypatch.setattr(f, "MSDeformAttnFunction", oracle.OracleMSDAFunction)
+    return oracle
