@@ -4,26 +4,34 @@
 // and ms_deform_attn_cuda.cu:20-80 (host) behind the C ABI in include/dfx_msda.h.
 //
 // The reference gives one THREAD one output channel (1024-thread blocks, int64 shape loads and
-// scalar 4-byte gathers per thread).  Here the unit of work is a WAVE:
+// scalar 4-byte gathers per thread, every thread redoing the sample geometry).  Here the unit of
+// work is a WAVE and the work is split in two phases (production geometry M=8 heads x D=32
+// channels, P=4 points, fp32):
 //
-//   one wave64 = one query; lane = (head m = lane>>3, channel quad cg = lane&7)
+//   phase A  "taps": lane = one (query, level, point, head) sample of the wave's 2 queries.  It
+//            loads its (x, y, weight) triple - the 64 lanes read 768 contiguous bytes - and does
+//            the geometry ONCE: skip rule, floor, corner validity, 4 byte offsets, 4 weights
+//            premultiplied by the attention weight.  Taps go to LDS in [query][level][point][head]
+//            order (32 bytes each; two 16-byte stores).
+//   phase B  "gather": lane = (head m = lane>>3, channel quad cg = lane&7).  Per point it reads
+//            its head's tap back as two 16-byte LDS broadcasts (8 distinct addresses, 128
+//            contiguous bytes: conflict-free), then issues the 4 corner fetches as 16-byte loads
+//            with a wave-uniform base + 32-bit offset; the 8 lanes of a head read one contiguous
+//            128-byte value row, so a wave-instruction touches 8 rows.  16 gathers per level are
+//            in flight before the first FMA; the reduction over L*P samples stays in registers
+//            and the query's 1 KiB output row leaves as one float4 per lane.
 //
-// so for the production geometry (M=8 heads x D=32 channels, fp32) a wave covers the whole 1 KiB
-// output row of its query with one float4 per lane, and every bilinear corner fetch is a 16-byte
-// load in which the 8 lanes of a head read one contiguous 128-byte value row (8 rows per
-// wave-instruction).  Per level the wave issues 4 points x 4 corners = 16 independent float4
-// gathers before any FMA consumes them (addresses are clamped instead of branched around, so the
-// compiler can keep all of them in flight), the (x,y,w) triples of the query are fetched as
-// three 16-byte loads per lane (the 8 lanes of a head read the same address: one request), and
-// the per-query reduction over L*P samples happens in registers - no LDS, no cross-lane traffic.
-// A 256-thread workgroup holds 4 consecutive queries; workgroups are remapped so that each XCD
-// walks a contiguous raster range of queries and its private L2 holds only that band of the
-// value map (dfx_common.h).
+// A 256-thread workgroup holds 4 waves x 2 queries = 8 consecutive queries (x `iters`);
+// workgroups are remapped so that each XCD walks a contiguous raster range of queries and its
+// private L2 holds only that band of the value map (dfx_common.h).  The earlier one-phase form
+// (every lane redoing the geometry) measured VALU-bound at ~1000 instructions per query; it is
+// kept below only for P != 4.
 //
 // Roofline: HBM-bound gather.  Algorithmic bytes per call
 //   4 * (N*S*M*D  +  3*N*Lq*M*L*P  +  N*Lq*M*D)       (value + loc/aw + out, fp32)
 // = 10.21 MB per frame for the encoder geometry (S = Lq = 4200, L = 1).
 #include "dfx_common.h"
+#include "msda_tap.h"
 
 namespace {
 
@@ -49,13 +57,12 @@ __device__ __forceinline__ Corner4 corners(float lx, float ly, float a, int H, i
     const int h1 = h0 + 1, w1 = w0 + 1;
     const float lh = h_im - hf, lw = w_im - wf;
     const float hh = 1.f - lh, hw = 1.f - lw;
-    const bool top = h0 >= 0, bot = h1 <= H - 1, lef = w0 >= 0, rig = w1 <= W - 1;
-    const float s = inr ? a : 0.f;
+    const bool top = inr && h0 >= 0, bot = inr && h1 <= H - 1, lef = w0 >= 0, rig = w1 <= W - 1;
     Corner4 c;
-    c.w00 = (top && lef) ? hh * hw * s : 0.f;
-    c.w01 = (top && rig) ? hh * lw * s : 0.f;
-    c.w10 = (bot && lef) ? lh * hw * s : 0.f;
-    c.w11 = (bot && rig) ? lh * lw * s : 0.f;
+    c.w00 = (top && lef) ? hh * hw * a : 0.f;
+    c.w01 = (top && rig) ? hh * lw * a : 0.f;
+    c.w10 = (bot && lef) ? lh * hw * a : 0.f;
+    c.w11 = (bot && rig) ? lh * lw * a : 0.f;
     const int y0 = min(max(h0, 0), H - 1), y1 = min(max(h1, 0), H - 1);
     const int x0 = min(max(w0, 0), W - 1), x1 = min(max(w1, 0), W - 1);
     c.o00 = (y0 * W + x0) * row_stride;
@@ -65,13 +72,8 @@ __device__ __forceinline__ Corner4 corners(float lx, float ly, float a, int H, i
     return c;
 }
 
-__device__ __forceinline__ void fma4(float4 &acc, float w, const float4 &v)
-{
-    acc.x = fmaf(w, v.x, acc.x);
-    acc.y = fmaf(w, v.y, acc.y);
-    acc.z = fmaf(w, v.z, acc.z);
-    acc.w = fmaf(w, v.w, acc.w);
-}
+using dfx::fma4;
+using dfx::Tap;
 
 // ---------------------------------------------------------------------------------------------
 // Fast path: M = 8, D = 32, fp32, 16-byte aligned buffers.  PT = points per level at compile
@@ -137,6 +139,80 @@ __global__ __launch_bounds__(256) void msda_fwd_m8d32(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fast path: M = 8, D = 32, P = 4, fp32, LT levels (1..4) known at compile time.
+// ---------------------------------------------------------------------------------------------
+template <int LT>
+__global__ __launch_bounds__(256) void msda_fwd_taps(const float *__restrict__ value,
+                                                     const int64_t *__restrict__ shapes,
+                                                     const int64_t *__restrict__ lsi,
+                                                     const float *__restrict__ loc,
+                                                     const float *__restrict__ aw, int NQ, int Lq,
+                                                     int S, int iters, float *__restrict__ out)
+{
+    constexpr int QW = 2;                 // queries per wave per iteration
+    constexpr int TAPS = QW * LT * 32;    // taps per wave per iteration (multiple of 64)
+    __shared__ uint4 s_off[4][TAPS];
+    __shared__ float4 s_w[4][TAPS];
+    // wave index as a scalar: everything derived from it (query index, batch element, the value
+    // slab pointer) then lives in SGPRs and the gathers use scalar-base + 32-bit-offset addressing
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint4 *toff = s_off[wave];
+    float4 *tw = s_w[wave];
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int m = lane >> 3;
+    const unsigned lane_b = (unsigned)(lane & 7) * 16u;
+
+    int Hs[LT], Ws[LT], Rs[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        Hs[l] = (int)shapes[2 * l];
+        Ws[l] = (int)shapes[2 * l + 1];
+        Rs[l] = (int)lsi[l];
+    }
+
+    for (int it = 0; it < iters; ++it) {
+        const int q0 = ((blk * iters + it) * 4 + wave) * QW;   // first query of this wave (uniform)
+        if (q0 >= NQ) break;
+        // ---- phase A: one tap per lane ----
+#pragma unroll
+        for (int c = 0; c < TAPS / 64; ++c) {
+            const int s = c * 64 + lane;                 // slot = ((qq*LT + l)*4 + p)*8 + head
+            const int hm = s & 7, p = (s >> 3) & 3, ql = s >> 5;
+            const int l = (LT == 1) ? 0 : ql % LT, qq = (LT == 1) ? ql : ql / LT;
+            const int qi = q0 + qq;
+            Tap t;
+            if (qi < NQ) {
+                const long e = (((long)qi * 8 + hm) * LT + l) * 4 + p;
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + e * 2);
+                int H = Hs[0], W = Ws[0], R = Rs[0];
+#pragma unroll
+                for (int k = 1; k < LT; ++k)
+                    if (l == k) { H = Hs[k]; W = Ws[k]; R = Rs[k]; }
+                t = dfx::make_tap(xy.x, xy.y, aw[e], H, W, R, hm * 128);
+            } else {
+                t.off = make_uint4(0u, 0u, 0u, 0u);
+                t.w = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            toff[s] = t.off;
+            tw[s] = t.w;
+        }
+        dfx::wave_lds_fence();
+        // ---- phase B: gather, one query at a time ----
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq) {
+            const int qi = q0 + qq;
+            if (qi < NQ) {
+                const int b = qi / Lq;
+                const char *vb = reinterpret_cast<const char *>(value) + (size_t)b * S * 1024;
+                const float4 acc = dfx::gather_query<LT>(vb, lane_b, m, toff + qq * LT * 32, tw + qq * LT * 32);
+                *reinterpret_cast<float4 *>(out + (long)qi * 256 + lane * 4) = acc;
+            }
+        }
+        dfx::wave_lds_fence();   // the next iteration overwrites the taps
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic path: any M, D, L, P; fp32 and fp64.  One thread per output element, channel fastest
 // (adjacent lanes read adjacent channels of the same value row), grid-stride.  Used by the
 // reference's tiny test fixture (M=D=2), odd head sizes and every fp64 call.
@@ -197,15 +273,34 @@ extern "C" int dfx_msda_forward_f32(const float *value, const int64_t *shapes, c
     if (rc == 1) return DFX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long nq = (long)N * Lq;
-    if (M == 8 && D == 32 && nq < (1L << 29) && dfx::aligned16(value) && dfx::aligned16(out) &&
-        (P != 4 || (dfx::aligned16(loc) && dfx::aligned16(aw)))) {
+    if (S == 0 || L == 0 || P == 0) {   // nothing to sample: the reference returns zeros
+        if (hipMemsetAsync(out, 0, sizeof(float) * nq * M * D, st) != hipSuccess)
+            return dfx::fail(DFX_ELAUNCH, "msda forward: memset failed");
+        return DFX_OK;
+    }
+    const bool fast = M == 8 && D == 32 && nq < (1L << 28) && (long)S * 1024 < (1L << 32) &&
+                      dfx::aligned16(value) && dfx::aligned16(out);
+    if (fast && P == 4 && L <= 4 && (reinterpret_cast<uintptr_t>(loc) & 7u) == 0) {
+        // 8 queries per workgroup and iteration; keep >= ~2048 workgroups in the grid when we can
+        int iters = 1;
+        while (iters < 8 && nq / (8L * iters * 2) >= 2048) iters *= 2;
+        const int grid = (int)((nq + 8L * iters - 1) / (8L * iters));
+#define DFX_LAUNCH(LT)                                                                              \
+        hipLaunchKernelGGL((msda_fwd_taps<LT>), dim3(grid), dim3(256), 0, st, value, shapes, lsi, loc, \
+                           aw, (int)nq, Lq, S, iters, out)
+        switch (L) {
+            case 1: DFX_LAUNCH(1); break;
+            case 2: DFX_LAUNCH(2); break;
+            case 3: DFX_LAUNCH(3); break;
+            default: DFX_LAUNCH(4); break;
+        }
+#undef DFX_LAUNCH
+        return dfx::check_launch("msda_fwd_taps");
+    }
+    if (fast) {
         const int grid = (int)((nq + 3) / 4);
-        if (P == 4)
-            hipLaunchKernelGGL((msda_fwd_m8d32<4, true>), dim3(grid), dim3(256), 0, st, value, shapes,
-                               lsi, loc, aw, (int)nq, Lq, S, L, P, out);
-        else
-            hipLaunchKernelGGL((msda_fwd_m8d32<0, true>), dim3(grid), dim3(256), 0, st, value, shapes,
-                               lsi, loc, aw, (int)nq, Lq, S, L, P, out);
+        hipLaunchKernelGGL((msda_fwd_m8d32<0, true>), dim3(grid), dim3(256), 0, st, value, shapes, lsi,
+                           loc, aw, (int)nq, Lq, S, L, P, out);
         return dfx::check_launch("msda_fwd_m8d32");
     }
     const long total = nq * M * D;

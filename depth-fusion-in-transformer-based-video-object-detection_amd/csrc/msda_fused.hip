@@ -5,10 +5,10 @@
 // location arithmetic  ref + offset / normaliser, and only then the sampling kernel - five
 // elementwise launches and two HBM round trips of sampling_locations / attention_weights
 // (3 * N*Lq*M*L*P floats written and read back).  This kernel consumes the two Linear outputs
-// directly: same wave = query, lane = (head, channel quad) mapping as msda_forward.hip; each lane
-// recomputes its head's softmax (L*P <= 16 exponentials) and its 2*L*P location values in
-// registers - redundantly across the 8 lanes of a head, which is cheaper than a cross-lane
-// exchange at these sizes - and goes straight to the 16-byte corner gathers.
+// directly, in the two-phase structure of msda_forward.hip: in phase A each lane owns one
+// (query, level, point, head) sample, computes its softmax weight (the L*P logits of its head are
+// one or a few 16-byte loads; <= 16 exponentials) and its location, and stages the resulting tap
+// in LDS; phase B is the shared 16-byte corner gather (msda_tap.h).
 //
 // `Lr` is the number of reference-point levels.  Lr == L is the normal module.  Lr > L (with
 // L == 1) is the TransVOD temporal decoder: the module there builds a location tensor
@@ -16,132 +16,119 @@
 // ms_deform_attn_cuda.cu:45-48); row j of that flat view is (query j/(Lr*M), head (j/Lr)%M,
 // level j%Lr) of the tensor the module built, which is what `src_row` below reproduces.
 #include "dfx_common.h"
+#include "msda_tap.h"
 
 namespace {
 
+using dfx::Tap;
 using dfx::xcd_remap;
 
-struct Tap {
-    int o00, o01, o10, o11;
-    float w00, w01, w10, w11;
-};
-
-__device__ __forceinline__ Tap make_tap(float lx, float ly, float a, int H, int W)
-{
-    const float h_im = ly * (float)H - 0.5f;
-    const float w_im = lx * (float)W - 0.5f;
-    const bool inr = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-    const float hf = floorf(fminf(fmaxf(h_im, -1.f), (float)H));
-    const float wf = floorf(fminf(fmaxf(w_im, -1.f), (float)W));
-    const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
-    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-    const float s = inr ? a : 0.f;
-    Tap t;
-    t.w00 = (h0 >= 0 && w0 >= 0) ? hh * hw * s : 0.f;
-    t.w01 = (h0 >= 0 && w1 <= W - 1) ? hh * lw * s : 0.f;
-    t.w10 = (h1 <= H - 1 && w0 >= 0) ? lh * hw * s : 0.f;
-    t.w11 = (h1 <= H - 1 && w1 <= W - 1) ? lh * lw * s : 0.f;
-    const int y0 = min(max(h0, 0), H - 1), y1 = min(max(h1, 0), H - 1);
-    const int x0 = min(max(w0, 0), W - 1), x1 = min(max(w1, 0), W - 1);
-    t.o00 = (y0 * W + x0) * 256;
-    t.o01 = (y0 * W + x1) * 256;
-    t.o10 = (y1 * W + x0) * 256;
-    t.o11 = (y1 * W + x1) * 256;
-    return t;
-}
-
-__device__ __forceinline__ void fma4(float4 &acc, float w, const float4 &v)
-{
-    acc.x = fmaf(w, v.x, acc.x);
-    acc.y = fmaf(w, v.y, acc.y);
-    acc.z = fmaf(w, v.z, acc.z);
-    acc.w = fmaf(w, v.w, acc.w);
-}
-
+// Same two-phase structure as msda_fwd_taps (msda_forward.hip): phase A builds one tap per lane -
+// here from the raw Linear outputs - and stages it in LDS; phase B is the shared gather.
 // LT = levels at compile time (1..4), P = 4, M = 8, D = 32, fp32.
 template <int LT, int REFDIM>
-__global__ __launch_bounds__(256) void msda_fused_m8d32p4(const float *__restrict__ value,
-                                                          const int64_t *__restrict__ shapes,
-                                                          const int64_t *__restrict__ lsi,
-                                                          const float *__restrict__ ref, int Lr,
-                                                          const float *__restrict__ off, long off_stride,
-                                                          const float *__restrict__ logits, long logit_stride,
-                                                          int NQ, int Lq, int S, float *__restrict__ out)
+__global__ __launch_bounds__(256) void msda_fused_taps(const float *__restrict__ value,
+                                                       const int64_t *__restrict__ shapes,
+                                                       const int64_t *__restrict__ lsi,
+                                                       const float *__restrict__ ref, int Lr,
+                                                       const float *__restrict__ off, long off_stride,
+                                                       const float *__restrict__ logits, long logit_stride,
+                                                       int NQ, int Lq, int S, int iters,
+                                                       float *__restrict__ out)
 {
+    constexpr int QW = 2;
+    constexpr int TAPS = QW * LT * 32;
+    __shared__ uint4 s_off[4][TAPS];
+    __shared__ float4 s_w[4][TAPS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint4 *toff = s_off[wave];
+    float4 *tw = s_w[wave];
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int lane = threadIdx.x & 63;
-    const int qi = blk * 4 + (threadIdx.x >> 6);
-    if (qi >= NQ) return;
-    const int m = lane >> 3, cg = lane & 7;
-    const int b = qi / Lq;
-    const float *vb = value + (long)b * S * 256 + m * 32 + cg * 4;
+    const int m = lane >> 3;
+    const unsigned lane_b = (unsigned)(lane & 7) * 16u;
 
-    // ---- softmax over the L*P logits of (query, head): F.softmax(x, -1) ----
-    float4 e[LT];
-    const float *lg = logits + (long)qi * logit_stride + m * (LT * 4);
-    float mx = -INFINITY;
+    int Hs[LT], Ws[LT], Rs[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
-        e[l] = *reinterpret_cast<const float4 *>(lg + l * 4);
-        mx = fmaxf(mx, fmaxf(fmaxf(e[l].x, e[l].y), fmaxf(e[l].z, e[l].w)));
+        Hs[l] = (int)shapes[2 * l];
+        Ws[l] = (int)shapes[2 * l + 1];
+        Rs[l] = (int)lsi[l];
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < LT; ++l) {
-        e[l].x = expf(e[l].x - mx); e[l].y = expf(e[l].y - mx);
-        e[l].z = expf(e[l].z - mx); e[l].w = expf(e[l].w - mx);
-        sum += e[l].x; sum += e[l].y; sum += e[l].z; sum += e[l].w;
-    }
-    const float inv = 1.f / sum;
 
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long i = (long)qi * 8 + m;     // flat (b,q,m)
+    for (int it = 0; it < iters; ++it) {
+        const int q0 = ((blk * iters + it) * 4 + wave) * QW;
+        if (q0 >= NQ) break;
 #pragma unroll
-    for (int l = 0; l < LT; ++l) {
-        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-        if (H <= 0 || W <= 0) continue;
-        const float *vl = vb + (long)((int)lsi[l]) * 256;
-        // which (query, head, reference level) the flat row i*L+l of the location tensor is
-        const long j = i * LT + l;
-        const int r = (int)(j % Lr);
-        const int ms = (int)((j / Lr) & 7);
-        const long qs = j / ((long)Lr * 8);
-        const int lo = (Lr == LT) ? r : 0;
-        const float *rp = ref + (qs * Lr + r) * REFDIM;
-        const float *op = off + qs * off_stride + (ms * LT + lo) * 8;
-        const float4 oa = *reinterpret_cast<const float4 *>(op);
-        const float4 ob = *reinterpret_cast<const float4 *>(op + 4);
-        float x0, y0, x1, y1, x2, y2, x3, y3;
-        if (REFDIM == 2) {
-            // ref + off / (W_lo, H_lo)   (ms_deform_attn.py:102-107)
-            const float nw = (float)shapes[2 * lo + 1], nh = (float)shapes[2 * lo];
-            const float rx = rp[0], ry = rp[1];
-            x0 = rx + oa.x / nw; y0 = ry + oa.y / nh; x1 = rx + oa.z / nw; y1 = ry + oa.w / nh;
-            x2 = rx + ob.x / nw; y2 = ry + ob.y / nh; x3 = rx + ob.z / nw; y3 = ry + ob.w / nh;
-        } else {
-            // ref_xy + off / P * ref_wh * 0.5   (ms_deform_attn.py:108-110)
-            const float4 rr = *reinterpret_cast<const float4 *>(rp);
-            x0 = rr.x + oa.x / 4.f * rr.z * 0.5f; y0 = rr.y + oa.y / 4.f * rr.w * 0.5f;
-            x1 = rr.x + oa.z / 4.f * rr.z * 0.5f; y1 = rr.y + oa.w / 4.f * rr.w * 0.5f;
-            x2 = rr.x + ob.x / 4.f * rr.z * 0.5f; y2 = rr.y + ob.y / 4.f * rr.w * 0.5f;
-            x3 = rr.x + ob.z / 4.f * rr.z * 0.5f; y3 = rr.y + ob.w / 4.f * rr.w * 0.5f;
+        for (int c = 0; c < TAPS / 64; ++c) {
+            const int s = c * 64 + lane;                 // slot = ((qq*LT + l)*4 + p)*8 + head
+            const int hm = s & 7, p = (s >> 3) & 3, ql = s >> 5;
+            const int l = (LT == 1) ? 0 : ql % LT, qq = (LT == 1) ? ql : ql / LT;
+            const int qi = q0 + qq;
+            Tap t;
+            if (qi < NQ) {
+                // ---- attention weight: softmax over the L*P logits of (query, head), F.softmax(x,-1)
+                const float *lg = logits + (long)qi * logit_stride + hm * (LT * 4);
+                float4 e[LT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < LT; ++k) {
+                    e[k] = *reinterpret_cast<const float4 *>(lg + k * 4);
+                    mx = fmaxf(mx, fmaxf(fmaxf(e[k].x, e[k].y), fmaxf(e[k].z, e[k].w)));
+                }
+                float sum = 0.f, mine = 0.f;
+#pragma unroll
+                for (int k = 0; k < LT; ++k) {
+                    const float ex = expf(e[k].x - mx), ey = expf(e[k].y - mx);
+                    const float ez = expf(e[k].z - mx), ew = expf(e[k].w - mx);
+                    sum += ex; sum += ey; sum += ez; sum += ew;
+                    if (k == l) mine = (p == 0) ? ex : (p == 1) ? ey : (p == 2) ? ez : ew;
+                }
+                const float a = mine / sum;
+                // ---- location: which (query, head, reference level) flat row i*L+l of the location
+                //      tensor [N,Lq,M,Lr,P,2] is (identity when Lr == L)
+                const long j = ((long)qi * 8 + hm) * LT + l;
+                const int r = (int)(j % Lr);
+                const int ms = (int)((j / Lr) & 7);
+                const long qs = j / ((long)Lr * 8);
+                const int lo = (Lr == LT) ? r : 0;
+                const float *rp = ref + (qs * Lr + r) * REFDIM;
+                const float2 o2 = *reinterpret_cast<const float2 *>(off + qs * off_stride + ((ms * LT + lo) * 4 + p) * 2);
+                int H = Hs[0], W = Ws[0], R = Rs[0];
+#pragma unroll
+                for (int k = 1; k < LT; ++k)
+                    if (l == k) { H = Hs[k]; W = Ws[k]; R = Rs[k]; }
+                float x, y;
+                if (REFDIM == 2) {
+                    // ref + off / (W_lo, H_lo)   (ms_deform_attn.py:102-107); lo == l unless Lr != L (then L == 1)
+                    x = rp[0] + o2.x / (float)W;
+                    y = rp[1] + o2.y / (float)H;
+                } else {
+                    // ref_xy + off / P * ref_wh * 0.5   (ms_deform_attn.py:108-110)
+                    const float4 rr = *reinterpret_cast<const float4 *>(rp);
+                    x = rr.x + o2.x / 4.f * rr.z * 0.5f;
+                    y = rr.y + o2.y / 4.f * rr.w * 0.5f;
+                }
+                t = dfx::make_tap(x, y, a, H, W, R, hm * 128);
+            } else {
+                t.off = make_uint4(0u, 0u, 0u, 0u);
+                t.w = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            toff[s] = t.off;
+            tw[s] = t.w;
         }
-        const Tap t0 = make_tap(x0, y0, e[l].x * inv, H, W);
-        const Tap t1 = make_tap(x1, y1, e[l].y * inv, H, W);
-        const Tap t2 = make_tap(x2, y2, e[l].z * inv, H, W);
-        const Tap t3 = make_tap(x3, y3, e[l].w * inv, H, W);
-#define DFX_LD(t, o) (*reinterpret_cast<const float4 *>(vl + t.o))
-        const float4 v00 = DFX_LD(t0, o00), v01 = DFX_LD(t0, o01), v02 = DFX_LD(t0, o10), v03 = DFX_LD(t0, o11);
-        const float4 v10 = DFX_LD(t1, o00), v11 = DFX_LD(t1, o01), v12 = DFX_LD(t1, o10), v13 = DFX_LD(t1, o11);
-        const float4 v20 = DFX_LD(t2, o00), v21 = DFX_LD(t2, o01), v22 = DFX_LD(t2, o10), v23 = DFX_LD(t2, o11);
-        const float4 v30 = DFX_LD(t3, o00), v31 = DFX_LD(t3, o01), v32 = DFX_LD(t3, o10), v33 = DFX_LD(t3, o11);
-#undef DFX_LD
-        fma4(acc, t0.w00, v00); fma4(acc, t0.w01, v01); fma4(acc, t0.w10, v02); fma4(acc, t0.w11, v03);
-        fma4(acc, t1.w00, v10); fma4(acc, t1.w01, v11); fma4(acc, t1.w10, v12); fma4(acc, t1.w11, v13);
-        fma4(acc, t2.w00, v20); fma4(acc, t2.w01, v21); fma4(acc, t2.w10, v22); fma4(acc, t2.w11, v23);
-        fma4(acc, t3.w00, v30); fma4(acc, t3.w01, v31); fma4(acc, t3.w10, v32); fma4(acc, t3.w11, v33);
+        dfx::wave_lds_fence();
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq) {
+            const int qi = q0 + qq;
+            if (qi < NQ) {
+                const int b = qi / Lq;
+                const char *vb = reinterpret_cast<const char *>(value) + (size_t)b * S * 1024;
+                const float4 acc = dfx::gather_query<LT>(vb, lane_b, m, toff + qq * LT * 32, tw + qq * LT * 32);
+                *reinterpret_cast<float4 *>(out + (long)qi * 256 + lane * 4) = acc;
+            }
+        }
+        dfx::wave_lds_fence();
     }
-    *reinterpret_cast<float4 *>(out + (long)qi * 256 + m * 32 + cg * 4) = acc;
 }
 
 template <int LT>
@@ -149,14 +136,16 @@ int launch(int ref_dim, const float *value, const int64_t *shapes, const int64_t
            int Lr, const float *off, long off_stride, const float *logits, long logit_stride, int NQ,
            int Lq, int S, float *out, hipStream_t st)
 {
-    const dim3 grid((NQ + 3) / 4), block(256);
+    int iters = 1;
+    while (iters < 8 && NQ / (8L * iters * 2) >= 2048) iters *= 2;
+    const dim3 grid((unsigned)((NQ + 8L * iters - 1) / (8L * iters))), block(256);
     if (ref_dim == 2)
-        hipLaunchKernelGGL((msda_fused_m8d32p4<LT, 2>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
-                           off_stride, logits, logit_stride, NQ, Lq, S, out);
+        hipLaunchKernelGGL((msda_fused_taps<LT, 2>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
+                           off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
     else
-        hipLaunchKernelGGL((msda_fused_m8d32p4<LT, 4>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
-                           off_stride, logits, logit_stride, NQ, Lq, S, out);
-    return dfx::check_launch("msda_fused_m8d32p4");
+        hipLaunchKernelGGL((msda_fused_taps<LT, 4>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
+                           off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
+    return dfx::check_launch("msda_fused_taps");
 }
 
 }  // namespace
@@ -183,7 +172,12 @@ extern "C" int dfx_msda_fused_forward_f32(const float *value, const int64_t *sha
         (ref_dim == 4 && !dfx::aligned16(ref)))
         return dfx::fail(DFX_EINVAL, "msda fused: buffers must be 16-byte aligned");
     const long nq = (long)N * Lq;
-    if (nq >= (1L << 29)) return dfx::fail(DFX_ERANGE, "msda fused: too many queries");
+    if (nq >= (1L << 28) || (long)S * 1024 >= (1L << 32)) return dfx::fail(DFX_ERANGE, "msda fused: problem too large");
+    if (S == 0) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * nq * M * D, static_cast<hipStream_t>(stream)) != hipSuccess)
+            return dfx::fail(DFX_ELAUNCH, "msda fused: memset failed");
+        return DFX_OK;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (L) {
         case 1: return launch<1>(ref_dim, value, shapes, lsi, ref, Lr, off, off_stride, logits, logit_stride, (int)nq, Lq, S, out, st);
