@@ -128,3 +128,32 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
     _lib.check(rc, "msda_fused_forward")
     return out
+
+
+def roi_align(inp, rois, output_size, spatial_scale, sampling_ratio, aligned=True, channels_last=False):
+    """RoIAlign (avg, fixed sampling grid) through include/dfx_roi.h.
+
+    channels_last=False: inp [N,C,H,W] contiguous -> [K,C,ph,pw]
+    channels_last=True : inp [N,H,W,C] contiguous -> [K,ph*pw,C]   (token-major memory, no transpose)
+    rois [K,5] = (batch index, x1, y1, x2, y2)
+    """
+    lib = _lib.load()
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    rois = rois.contiguous().float()
+    _check_inputs([("input", inp), ("rois", rois)])
+    _require(inp.dtype == torch.float32, "roi_align is implemented for float32")
+    _require(rois.dim() == 2 and rois.shape[1] == 5, "rois must be [K,5]")
+    K = rois.shape[0]
+    if channels_last:
+        N, H, W, C = inp.shape
+        out = torch.empty((K, ph * pw, C), dtype=inp.dtype, device=inp.device)
+        fn = lib.dfx_roi_align_nhwc_f32
+    else:
+        N, C, H, W = inp.shape
+        out = torch.empty((K, C, ph, pw), dtype=inp.dtype, device=inp.device)
+        fn = lib.dfx_roi_align_nchw_f32
+    with torch.cuda.device(inp.device):
+        rc = fn(inp.data_ptr(), rois.data_ptr(), N, C, H, W, K, ph, pw, float(spatial_scale),
+                int(sampling_ratio), int(bool(aligned)), out.data_ptr(), _stream(inp.device))
+    _lib.check(rc, "roi_align")
+    return out

@@ -1,0 +1,198 @@
+"""TransVOD++ transformer with RGB-D fusion (ref models/deformable_transformer_multi_plusplus.py).
+
+The batch axis of the inputs is the clip: frame 0 is the current frame, frames 1..R are reference
+frames.  The spatial stage (Late Fusion / encoder / decoder) runs on all T = 1+R frames and is
+shared with the single-frame model (``SpatialTransformerBase``).  The temporal stage (ref :401-601)
+
+  per frame   class logits and boxes from the last decoder layer, 300 RoIs on the frame's encoder
+              memory (current frame: plain memory; reference frames: memory + positional
+              embedding), RoIAlign 7x7, query/RoI fusion ``dynamic_layer_for_current_query1``
+  per clip    3 x [ top-(k*R) reference queries by class-1 score, k = 80/50/30 -> gather ->
+              ``temporal_query_layer{i}`` (TQE) -> ``temporal_decoder{i}`` (TDTD) on the current memory ]
+
+is written here as two functions, ``frame_stage`` and ``temporal_stage``, so that a clip whose
+frames are spread over several GPUs can exchange just the per-frame results (parallel/clip_shard.py).
+``forward`` composes them exactly as the reference does for one clip on one device.
+
+Quirks of the reference that are kept (SURVEY.md sections 0.6 and 8a, row a11): the temporal
+decoders get [1,300,R,4] reference boxes against a 1-level value map (flat read of the location
+tensor); RoIAlign runs with spatial_scale 1/32 on the stride-16 map; the (h, w) used to view the
+memory as a map are those of the last depth level under Late Fusion; only
+``dynamic_layer_for_current_query1`` is used, ``...query2/3`` exist for checkpoint compatibility.
+"""
+import torch
+from torch import nn
+
+from util import box_ops
+from util.misc import inverse_sigmoid
+
+from .deformable_transformer_single import SpatialTransformerBase
+from .roi_align import RoIAlign
+from .sparse_roi_head.head import RCNNHead
+from .transformer_layers import (DeformableTransformerDecoder, DeformableTransformerDecoderLayer,  # noqa: F401
+                                 DeformableTransformerEncoder, DeformableTransformerEncoderLayer,
+                                 DeformableTransformerFusionLayerV2, DepthDeformableTransformerEncoderLayer,
+                                 RGBDDeformableTransformerEncoderV2, TemporalDeformableTransformerDecoder,
+                                 TemporalDeformableTransformerEncoderLayer, TemporalQueryEncoder,
+                                 TemporalQueryEncoderLayer, _get_activation_fn, _get_clones,
+                                 get_reference_points, get_valid_ratio)
+
+TOPK_PER_REF = (80, 50, 30)
+
+
+def get_box_tensor(boxes):
+    return boxes.tensor if hasattr(boxes, "tensor") else boxes
+
+
+def bbox2roi(bbox_list):
+    """list of [n_i,4] boxes (one entry per image) -> [sum n_i, 5] rows (image index, x1, y1, x2, y2)."""
+    rows = []
+    for img_id, boxes in enumerate(bbox_list):
+        boxes = get_box_tensor(boxes)
+        rows.append(torch.cat([boxes.new_full((boxes.size(0), 1), img_id), boxes], dim=-1))
+    return torch.cat(rows, 0)
+
+
+class DeformableTransformer(SpatialTransformerBase):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
+                 dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=300, num_query=300,
+                 n_temporal_decoder_layers=1, num_ref_frames=3, fixed_pretrained_model=False, args=None,
+                 use_depth=False, depth_type="", dpth_feature_levels=1, dpth_n_points=4):
+        super().__init__()
+        self.num_ref_frames = num_ref_frames
+        self.fixed_pretrained_model = fixed_pretrained_model
+        self.n_temporal_query_layers = 3
+        self.num_query = num_query
+        dec_layer = self._build_spatial(d_model, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward,
+                                        dropout, activation, return_intermediate_dec, num_feature_levels,
+                                        dec_n_points, enc_n_points, two_stage, two_stage_num_proposals, use_depth,
+                                        depth_type, dpth_feature_levels, dpth_n_points)
+        self.temporal_roi_layers1 = nn.ModuleList(
+            [RoIAlign(output_size=7, spatial_scale=1 / s, sampling_ratio=2) for s in [32]])
+        self.cfg = {"MODEL": {"SparseRCNN": {"NHEADS": 8, "DROPOUT": 0.0, "DIM_FEEDFORWARD": 2048,
+                                              "ACTIVATION": "relu", "HIDDEN_DIM": d_model, "NUM_CLS": 1,
+                                              "NUM_REG": 3, "NUM_HEADS": 6, "NUM_DYNAMIC": 2, "DIM_DYNAMIC": 64},
+                              "ROI_BOX_HEAD": {"POOLER_RESOLUTION": 7}}}
+        for i in (1, 2, 3):
+            setattr(self, f"temporal_query_layer{i}",
+                    TemporalQueryEncoderLayer(d_model, dim_feedforward, dropout, activation, nhead))
+        for i in (1, 2, 3):
+            setattr(self, f"dynamic_layer_for_current_query{i}",
+                    RCNNHead(self.cfg, d_model, 3, dim_feedforward, nhead, dropout, activation))
+        for i in (1, 2, 3):
+            setattr(self, f"temporal_decoder{i}",
+                    TemporalDeformableTransformerDecoder(dec_layer, n_temporal_decoder_layers, False))
+        self._reset_parameters()
+
+    # ------------------------------------------------------------------------------------------
+    def frame_stage(self, hs_last, ref_last, memory, pos_embed, hw, imgs_whwh, class_embed, bbox_embed,
+                    roles=("cur", "ref")):
+        """Per-frame half of the temporal stage for F frames (any subset of a clip).
+
+        hs_last [F,Q,C] last decoder layer output, ref_last [F,Q,4] its reference boxes,
+        memory [F,S,C], pos_embed [F,S,C] (level-embedded positional embedding), hw = (h, w).
+        Returns a dict with, per frame:
+          logits [F,Q,classes]; boxes [F,Q,4] (sigmoid, cxcywh)
+          "cur": queries fused with RoI features of the plain memory          [F,Q,C]
+          "ref": queries fused with RoI features of memory + positional embedding [F,Q,C]
+        (ref :450-518; a frame needs "cur" when it is the current frame and "ref" when it serves
+        as a reference frame.)"""
+        h, w = hw
+        F_, Q, C = hs_last.shape
+        logits = class_embed(hs_last)
+        boxes = (bbox_embed(hs_last) + inverse_sigmoid(ref_last)).sigmoid()
+        xyxy = box_ops.box_cxcywh_to_xyxy(boxes) * imgs_whwh                      # image pixels
+        out = dict(logits=logits, boxes=boxes)
+        roi = self.temporal_roi_layers1[0]
+        head = self.dynamic_layer_for_current_query1
+        for role in roles:
+            mem = memory if role == "cur" else memory + pos_embed
+            fused = []
+            for f in range(F_):                     # the head's self-attention is per frame
+                rois = bbox2roi([xyxy[f]])
+                fmap = mem[f:f + 1].permute(0, 2, 1).unsqueeze(-1).view(1, C, h, w)   # channels-last view
+                feats = roi(fmap, rois)
+                fused.append(head(feats, hs_last[f:f + 1]))
+            out[role] = torch.cat(fused, 0)
+        return out
+
+    def temporal_stage(self, cur_hs, cur_reference_out, cur_memory, ref_hs_concat, ref_logits_concat,
+                       spatial_shapes, level_start_index, valid_ratio_cur, temp_class_embed_list,
+                       temp_bbox_embed_list):
+        """Per-clip half for ONE current frame (ref :525-601).
+
+        cur_hs [1,Q,C] ("cur" fused queries), cur_reference_out [1,Q,4], cur_memory [1,S,C],
+        ref_hs_concat [1,R*Q,C] ("ref" fused queries of the R reference frames, clip order),
+        ref_logits_concat [1,R*Q,classes], valid_ratio_cur [1,L,2] of the current frame.
+        -> final_hs [1,Q,C], final_references [1,Q,4], aux outputs, top-k indices."""
+        R = ref_hs_concat.shape[1] // cur_hs.shape[1]
+        score = ref_logits_concat.sigmoid()[:, :, 1]
+        ratios = valid_ratio_cur[:, :1].expand(1, R, 2)        # [1,R,2]: R "levels" of reference boxes
+        shapes1, lsi1 = spatial_shapes[0:1], level_start_index[0:1]
+        for attr in ("_dfx_host", "_dfx_tokens"):
+            if hasattr(spatial_shapes, attr) and spatial_shapes.shape[0] == 1:
+                setattr(shapes1, attr, getattr(spatial_shapes, attr))
+        aux, picks = [], []
+        final_hs, final_refs = cur_hs, cur_reference_out
+        for i, k in enumerate(TOPK_PER_REF):
+            idx = torch.topk(score, k * R, dim=1)[1]
+            picks.append(idx)
+            selected = torch.gather(ref_hs_concat, 1, idx.unsqueeze(-1).repeat(1, 1, ref_hs_concat.shape[-1]))
+            cur_hs = getattr(self, f"temporal_query_layer{i + 1}")(cur_hs, selected)
+            cur_hs, refs = getattr(self, f"temporal_decoder{i + 1}")(
+                cur_hs, cur_reference_out, cur_memory, shapes1, lsi1, ratios, None, None)
+            if i < 2:
+                box = temp_bbox_embed_list[i](cur_hs)
+                unact = inverse_sigmoid(refs)
+                if unact.shape[-1] == 4:
+                    box = box + unact
+                else:
+                    assert unact.shape[-1] == 2
+                    box[..., :2] += unact
+                aux.append({"pred_logits": temp_class_embed_list[i](cur_hs), "pred_boxes": box.sigmoid()})
+            else:
+                final_hs, final_refs = cur_hs, refs
+        return final_hs, final_refs, aux, picks
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, srcs, masks, pos_embeds, depth_srcs, depth_masks, depth_pos_embeds, imgs_whwh_shape,
+                query_embed=None, class_embed=None, cur_bbox_embed=None, temp_class_embed_list=None,
+                temp_bbox_embed_list=None, rgbd_query=[]):
+        s = self._spatial_stage(srcs, masks, pos_embeds, depth_srcs, depth_masks, depth_pos_embeds, query_embed,
+                                rgbd_query)
+        hs, init_ref, inter_refs = s["hs"], s["init_reference"], s["inter_references"]
+        if self.two_stage:
+            return hs, init_ref, inter_refs, s["enc_outputs_class"], s["enc_outputs_coord_unact"]
+        memory = s["memory"]
+        if self.fixed_pretrained_model:
+            memory, hs, inter_refs = memory.detach(), hs.detach(), inter_refs.detach()
+
+        T = self.num_ref_frames + 1
+        assert memory.shape[0] == T, f"expected a clip of {T} frames, got {memory.shape[0]}"
+        whwh = torch.as_tensor(imgs_whwh_shape, dtype=torch.long, device=memory.device).repeat(1, self.num_query, 1)
+        fs_cur = self.frame_stage(hs[-1][:1], inter_refs[-1][:1], memory[:1], s["lvl_pos_embed_flatten"][:1],
+                                  s["last_hw"], whwh, class_embed, cur_bbox_embed, roles=("cur",))
+        fs_ref = self.frame_stage(hs[-1][1:], inter_refs[-1][1:], memory[1:], s["lvl_pos_embed_flatten"][1:],
+                                  s["last_hw"], whwh, class_embed, cur_bbox_embed, roles=("ref",))
+        Q, C = hs.shape[2], hs.shape[3]
+        ref_hs_concat = fs_ref["ref"].reshape(1, self.num_ref_frames * Q, C)
+        ref_logits_concat = fs_ref["logits"].reshape(1, self.num_ref_frames * Q, -1)
+        final_hs, final_refs, aux, _ = self.temporal_stage(
+            fs_cur["cur"], inter_refs[-1][:1], memory[:1], ref_hs_concat, ref_logits_concat,
+            s["spatial_shapes"], s["level_start_index"], s["valid_ratios"][:1], temp_class_embed_list,
+            temp_bbox_embed_list)
+        out = {"aux_outputs": aux}
+        return hs[:, 0:1], init_ref[0:1], inter_refs[:, 0:1], None, None, final_hs, final_refs, out
+
+
+def build_deforamble_transformer(args):
+    return DeformableTransformer(
+        d_model=args.hidden_dim, nhead=args.nheads, num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers, dim_feedforward=args.dim_feedforward, dropout=args.dropout,
+        activation="relu", return_intermediate_dec=True, num_feature_levels=args.num_feature_levels,
+        dec_n_points=args.dec_n_points, enc_n_points=args.enc_n_points, two_stage=args.two_stage,
+        two_stage_num_proposals=args.num_queries, num_query=args.num_queries,
+        n_temporal_decoder_layers=args.n_temporal_decoder_layers, num_ref_frames=args.num_ref_frames,
+        fixed_pretrained_model=args.fixed_pretrained_model, args=args, use_depth=args.use_depth,
+        depth_type=args.depth_type, dpth_n_points=args.dpth_n_points)

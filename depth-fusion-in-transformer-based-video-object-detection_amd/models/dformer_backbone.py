@@ -1,0 +1,117 @@
+"""Depth backbone: the convolutional down-sampling path of DFormer
+(ref models/dformer_backbone.py).  One-channel depth -> 128 channels at stride 16:
+  stem   conv3x3/s2 (1->16) + BN + GELU + conv3x3/s2 (16->32) + BN
+  then   BN + conv3x3/s2 (32->64),  BN + conv3x3/s2 (64->128),  [BN + conv3x3/s2 (128->256)]
+The last stage exists (checkpoint keys) but the forward skips it (ref :142).  BatchNorm layers
+are live nn.BatchNorm2d: running statistics in eval mode.
+"""
+import os
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from util.misc import NestedTensor
+
+from .position_encoding import build_position_encoding
+
+
+class DownsamplePath(nn.Module):
+    def __init__(self, in_channels: int, dims: List[int], train_backbone: bool = True,
+                 freeze_batchnorm: bool = False):
+        super().__init__()
+        bn = lambda c: self._get_bn_layer(c, freeze_batchnorm)  # noqa: E731
+        self.downsample_layers_e = nn.ModuleList([nn.Sequential(
+            nn.Conv2d(in_channels, dims[0] // 2, kernel_size=3, stride=2, padding=1), bn(dims[0] // 2), nn.GELU(),
+            nn.Conv2d(dims[0] // 2, dims[0], kernel_size=3, stride=2, padding=1), bn(dims[0]))])
+        for a, b in zip(dims[:-1], dims[1:]):
+            self.downsample_layers_e.append(
+                nn.Sequential(bn(a), nn.Conv2d(a, b, kernel_size=3, stride=2, padding=1)))
+        if not train_backbone:
+            for p in self.downsample_layers_e.parameters():
+                p.requires_grad = False
+
+    @staticmethod
+    def _get_bn_layer(num_features, freeze_batchnorm):
+        layer = nn.BatchNorm2d(num_features)
+        if freeze_batchnorm:
+            layer.eval()
+            for p in layer.parameters():
+                p.requires_grad = False
+        return layer
+
+
+class DFormerBackbone(nn.Module):
+    def __init__(self, dims=(32, 64, 128, 256), train_backbone=True, return_interm_layers=False,
+                 pretrained_path=None, freeze_batchnorm=True, eval_mode=False):
+        super().__init__()
+        self.return_interm_layers = return_interm_layers
+        self.depth_backbone = DownsamplePath(1, list(dims), train_backbone, freeze_batchnorm)
+        self._reset_parameters()
+        self.strides = [2 ** (i + 2) for i in range(len(dims) - 1)]
+        self.num_channels = dims[1:]
+        if pretrained_path and not eval_mode:
+            self.load_pretrained_weights(self.depth_backbone, pretrained_path)
+
+    def _reset_parameters(self):
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.xavier_uniform_(mod.weight)
+                if mod.bias is not None:
+                    nn.init.constant_(mod.bias, 0)
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+
+    def forward(self, tensor_list: NestedTensor) -> Dict[str, NestedTensor]:
+        x, m = tensor_list.tensors, tensor_list.mask
+        assert m is not None, "Input mask is None."
+        out: Dict[str, NestedTensor] = {}
+        stages = self.depth_backbone.downsample_layers_e[:-1]        # the 4th stage is never run
+        for i, stage in enumerate(stages):
+            x = stage(x)
+            if self.return_interm_layers:
+                out[str(i)] = NestedTensor(x, F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0])
+        if not self.return_interm_layers:
+            out["0"] = NestedTensor(x, F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0])
+        return out
+
+    def load_pretrained_weights(self, model, pretrained_weights_path, prefix="downsample_layers_e"):
+        """Partial load of a DFormer checkpoint ({'state_dict': ...}): conv / BN affine tensors whose
+        key contains both ``prefix`` and the module's name; running statistics are left alone
+        (ref :161-198)."""
+        if not os.path.exists(pretrained_weights_path):
+            print(f"Invalid path for pretrained weights: {pretrained_weights_path}")
+            return
+        weights = torch.load(pretrained_weights_path, map_location="cpu")["state_dict"]
+        skip = ("running_mean", "running_var", "num_batches_tracked")
+        for name, mod in model.named_modules():
+            if not isinstance(mod, (nn.Conv2d, nn.BatchNorm2d)):
+                continue
+            for key, tensor in weights.items():
+                if prefix in key and name in key and not any(s in key for s in skip):
+                    if mod.weight.shape == tensor.shape:
+                        mod.weight.data = tensor.data.clone()
+                    if mod.bias is not None and "bias" in key:
+                        mod.bias.data = tensor.data.clone()
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        xs = self[0](tensor_list)
+        out = [x for _, x in sorted(xs.items())]
+        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        return out, pos
+
+
+def build_dformer_backbone(args) -> Joiner:
+    backbone = DFormerBackbone(dims=(32, 64, 128, 256), train_backbone=True, return_interm_layers=False,
+                               pretrained_path=getattr(args, "dformer_weights", None), freeze_batchnorm=False,
+                               eval_mode=False)
+    return Joiner(backbone, build_position_encoding(args))

@@ -1,0 +1,79 @@
+"""Query / RoI fusion head of TransVOD++ (Sparse R-CNN style), ref models/sparse_roi_head/head.py.
+
+``RCNNHead`` (:31-83): self-attention over the N*300 object queries, ``DynamicConv`` interaction
+with each query's 7x7 RoI feature, FFN.  ``DynamicConv`` (:127-172): every query generates two
+1x1 "conv" kernels (256x64 and 64x256) with one Linear 256 -> 2*256*64, applies them to its own
+49x256 RoI feature as two batched matmuls with LayerNorm+ReLU, flattens 49*256 and projects back
+to 256.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
+
+
+def _get_activation_fn(activation):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+class DynamicConv(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        sp = cfg["MODEL"]["SparseRCNN"]
+        self.hidden_dim, self.dim_dynamic, self.num_dynamic = sp["HIDDEN_DIM"], sp["DIM_DYNAMIC"], sp["NUM_DYNAMIC"]
+        self.num_params = self.hidden_dim * self.dim_dynamic
+        self.dynamic_layer = nn.Linear(self.hidden_dim, self.num_dynamic * self.num_params)
+        self.norm1 = nn.LayerNorm(self.dim_dynamic)
+        self.norm2 = nn.LayerNorm(self.hidden_dim)
+        self.activation = nn.ReLU(inplace=True)
+        res = cfg["MODEL"]["ROI_BOX_HEAD"]["POOLER_RESOLUTION"]
+        self.out_layer = nn.Linear(self.hidden_dim * res ** 2, self.hidden_dim)
+        self.norm3 = nn.LayerNorm(self.hidden_dim)
+
+    def forward(self, pro_features, roi_features):
+        """pro_features (1, K, C); roi_features (49, K, C) -> (K, C)."""
+        feats = roi_features.permute(1, 0, 2)                               # K,49,C
+        params = self.dynamic_layer(pro_features).permute(1, 0, 2)          # K,1,2*C*dd
+        k1 = params[:, :, : self.num_params].reshape(-1, self.hidden_dim, self.dim_dynamic)
+        k2 = params[:, :, self.num_params:].reshape(-1, self.dim_dynamic, self.hidden_dim)
+        feats = self.activation(self.norm1(torch.bmm(feats, k1)))
+        feats = self.activation(self.norm2(torch.bmm(feats, k2)))
+        feats = self.out_layer(feats.flatten(1))
+        return self.activation(self.norm3(feats))
+
+
+class RCNNHead(nn.Module):
+    def __init__(self, cfg, d_model, num_classes, dim_feedforward=2048, nhead=8, dropout=0.1, activation="relu",
+                 scale_clamp: float = _DEFAULT_SCALE_CLAMP, bbox_weights=(2.0, 2.0, 1.0, 1.0)):
+        super().__init__()
+        self.d_model = d_model
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.inst_interact = DynamicConv(cfg)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation = _get_activation_fn(activation)
+        self.scale_clamp, self.bbox_weights = scale_clamp, bbox_weights
+
+    def forward(self, roi_features, pro_features):
+        """roi_features (N*nr_boxes, C, 7, 7); pro_features (N, nr_boxes, C) -> (1, N*nr_boxes, C)."""
+        N, nr_boxes = pro_features.shape[:2]
+        roi = roi_features.view(N * nr_boxes, self.d_model, -1).permute(2, 0, 1)          # 49,K,C
+        q = pro_features.view(N, nr_boxes, self.d_model).permute(1, 0, 2)                 # nr,N,C
+        q = self.norm1(q + self.dropout1(self.self_attn(q, q, value=q)[0]))
+        q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
+        obj = self.norm2(q + self.dropout2(self.inst_interact(q, roi)))
+        y = self.linear2(self.dropout(self.activation(self.linear1(obj))))
+        return self.norm3(obj + self.dropout3(y))

@@ -1,0 +1,407 @@
+"""Transformer blocks that drive the MSDA operator, shared by the single-frame, TransVOD and
+TransVOD++ transformers (the reference repeats them in each of its three transformer files;
+parameter names below are the reference's, so checkpoints load unchanged).
+
+Reference (all under /root/reference/models/):
+  encoder layer / encoder        deformable_transformer_single.py:520-593
+  decoder layer / decoder        deformable_transformer_single.py:596-748
+  Late Fusion layer              deformable_transformer_single.py:341-402
+  Encoder-CrossFusion layer/enc  deformable_transformer_single.py:406-518
+  temporal query encoder layer   deformable_transformer_multi_plusplus.py:787-838
+  temporal MSDA encoder layer    deformable_transformer_multi_plusplus.py:853-901
+  temporal decoder               deformable_transformer_multi_plusplus.py:1030-1076
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from models.ops.modules import MSDeformAttn
+from util.misc import inverse_sigmoid
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _get_activation_fn(activation):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+def _add_pos(x, pos):
+    return x if pos is None else x + pos
+
+
+# ---- level bookkeeping: device tensors for the kernels, host copies for Python loops -------------
+def make_level_tensors(shape_list, device):
+    """(spatial_shapes i64 [L,2], level_start_index i64 [L]) on ``device`` from host (H,W) pairs.
+    The host list rides along (``_dfx_host``) so later code never reads sizes back from the GPU."""
+    shape_list = [(int(h), int(w)) for h, w in shape_list]
+    starts, acc = [], 0
+    for h, w in shape_list:
+        starts.append(acc)
+        acc += h * w
+    shapes = torch.as_tensor(shape_list, dtype=torch.long, device=device)
+    lsi = torch.as_tensor(starts, dtype=torch.long, device=device)
+    shapes._dfx_host = shape_list
+    shapes._dfx_tokens = acc
+    return shapes, lsi
+
+
+def host_shapes(spatial_shapes):
+    host = getattr(spatial_shapes, "_dfx_host", None)
+    return host if host is not None else [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
+
+
+def get_valid_ratio(mask):
+    """Fraction of each padded map that is image: [N,2] = (w_ratio, h_ratio)."""
+    _, H, W = mask.shape
+    valid_h = torch.sum(~mask[:, :, 0], 1)
+    valid_w = torch.sum(~mask[:, 0, :], 1)
+    return torch.stack([valid_w.float() / W, valid_h.float() / H], -1)
+
+
+def get_reference_points(spatial_shapes, valid_ratios, device):
+    """Pixel-centre grid of every level in valid-image coordinates, [N, sum(HW), L, 2]
+    (ref deformable_transformer_single.py:165-177)."""
+    per_level = []
+    for lvl, (H, W) in enumerate(host_shapes(spatial_shapes)):
+        ys = torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device)
+        xs = torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device)
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        gy = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+        gx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+        per_level.append(torch.stack((gx, gy), -1))
+    grid = torch.cat(per_level, 1)
+    return grid[:, :, None] * valid_ratios[:, None]
+
+
+# ---- encoder ----------------------------------------------------------------------------------------
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    with_pos_embed = staticmethod(_add_pos)
+
+    def forward_ffn(self, src):
+        y = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(y))
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
+                rgbd_src=None):
+        query = rgbd_src if rgbd_src is not None else _add_pos(src, pos)
+        y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + self.dropout1(y))
+        return self.forward_ffn(src)
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    get_reference_points = staticmethod(get_reference_points)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                rgbd_src=None):
+        out = src
+        ref = get_reference_points(spatial_shapes, valid_ratios, device=src.device)
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, rgbd_src=rgbd_src)
+        return out
+
+
+# ---- depth fusion blocks ----------------------------------------------------------------------------
+class _CrossFusionBlock(nn.Module):
+    """RGB tokens attend to depth tokens with MSDA:
+         src  = LN(Linear(depth))
+         tgt2 = Linear(MSDA(q = rgb + pos, ref = rgb grid, value = src))
+         tgt  = LN(tgt + tgt2);  tgt = LN(tgt + GELU(Linear(tgt)))
+    Late Fusion and Encoder Cross Fusion differ only in the name of the last LayerNorm."""
+
+    _ffn_norm = "norm3"
+    _ffn_drop = "dropout4"
+
+    def __init__(self, d_model, dropout, n_levels, n_heads, n_points):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_model)
+        self.activation = _get_activation_fn("gelu")
+        setattr(self, self._ffn_drop, nn.Dropout(dropout))
+        setattr(self, self._ffn_norm, nn.LayerNorm(d_model))
+        self.depth_scale_adapt = nn.Linear(d_model, d_model)
+        self.norm_depth_scale = nn.LayerNorm(d_model)
+        self.cross_scale_adapt = nn.Linear(d_model, d_model)
+
+    with_pos_embed = staticmethod(_add_pos)
+
+    def forward_ffn(self, tgt):
+        y = self.activation(self.linear1(tgt))
+        return getattr(self, self._ffn_norm)(tgt + getattr(self, self._ffn_drop)(y))
+
+    def _fuse(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask):
+        src = self.norm_depth_scale(self.depth_scale_adapt(src))
+        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                            src_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(self.cross_scale_adapt(y)))
+        return self.forward_ffn(tgt)
+
+
+class DepthDeformableTransformerEncoderLayer(_CrossFusionBlock):
+    """Late Fusion layer (ref deformable_transformer_single.py:341-402)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_depth_levels=1, n_heads=8,
+                 dpth_n_points=4, depth_self_attn=False, gate=True, adaptation_layers=True):
+        super().__init__(d_model, dropout, n_depth_levels, n_heads, dpth_n_points)
+        self.depth_self_attn = depth_self_attn
+        self.adaptation_layers = adaptation_layers
+
+    def forward(self, tgt, query_pos, src_pos, tgt_spatial_shapes, reference_points, depth_reference_points, src,
+                src_spatial_shapes, frame_start_index, tgt_padding_mask=None, src_padding_mask=None):
+        return self._fuse(tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
+                          src_padding_mask)
+
+
+class DeformableTransformerFusionLayerV2(_CrossFusionBlock):
+    """Encoder Cross Fusion layer (ref deformable_transformer_single.py:406-461)."""
+
+    _ffn_norm = "norm2"
+    _ffn_drop = "dropout3"
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="gelu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__(d_model, dropout, n_levels, n_heads, n_points)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask=None):
+        return self._fuse(tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                          src_padding_mask)
+
+
+class RGBDDeformableTransformerEncoderV2(nn.Module):
+    """RGB encoder with a fusion layer after the first ``depth_num_layers`` RGB layers; the fusion
+    layer's value is the previous fusion output (depth tokens at first) and its result is added to
+    the RGB stream (ref deformable_transformer_single.py:465-518)."""
+
+    def __init__(self, encoder_layer, fusion_encoder_layer, num_layers, depth_num_layers, fusion_num_layers,
+                 fusion_layers_order=[]):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.fusion_layers = _get_clones(fusion_encoder_layer, fusion_num_layers)
+        self.num_layers = num_layers
+        self.depth_num_layers = depth_num_layers
+        self.fusion_num_layers = fusion_num_layers
+        self.fusion_layers_order = list(fusion_layers_order) if len(fusion_layers_order) > 0 \
+            else list(range(fusion_num_layers))
+        assert len(self.fusion_layers_order) == self.fusion_num_layers, \
+            "The number of fusion layers should match the fusion layer count"
+
+    get_reference_points = staticmethod(get_reference_points)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                rgbd_src=None, depth_src=None, depth_spatial_shapes=None, depth_level_start_index=None,
+                depth_valid_ratios=None, depth_pos=None, depth_padding_mask=None):
+        out, fused = src, depth_src
+        ref = get_reference_points(spatial_shapes, valid_ratios, device=src.device)
+        for i, layer in enumerate(self.layers):
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+            if i < self.depth_num_layers and i in self.fusion_layers_order:
+                fusion = self.fusion_layers[self.fusion_layers_order.index(i)]
+                fused = fusion(out, pos, ref, fused, depth_spatial_shapes, depth_level_start_index, padding_mask)
+                out = out + fused
+        return out
+
+
+# ---- decoder ----------------------------------------------------------------------------------------
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    with_pos_embed = staticmethod(_add_pos)
+
+    def forward_ffn(self, tgt):
+        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(y))
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask=None):
+        qk = _add_pos(tgt, query_pos)
+        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(y))
+        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                            level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(y))
+        return self.forward_ffn(tgt)
+
+
+def _scale_reference(reference_points, valid_ratios):
+    if reference_points.shape[-1] == 4:
+        return reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+    assert reference_points.shape[-1] == 2
+    return reference_points[:, :, None] * valid_ratios[:, None]
+
+
+class DeformableTransformerDecoder(nn.Module):
+    """Stack of decoder layers with optional per-layer box refinement: after layer i the reference
+    boxes become sigmoid(bbox_embed[i](out) + inverse_sigmoid(ref)), detached
+    (ref deformable_transformer_single.py:703-748)."""
+
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.bbox_embed = None    # set by the detector (box refinement / two-stage)
+        self.class_embed = None
+
+    def _refine(self, lid, output, reference_points):
+        if self.bbox_embed is None:
+            return reference_points
+        delta = self.bbox_embed[lid](output)
+        if reference_points.shape[-1] == 4:
+            new = delta + inverse_sigmoid(reference_points)
+        else:
+            assert reference_points.shape[-1] == 2
+            new = delta
+            new[..., :2] = delta[..., :2] + inverse_sigmoid(reference_points)
+        return new.sigmoid().detach()
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        output = tgt
+        inter, inter_refs = [], []
+        for lid, layer in enumerate(self.layers):
+            ref_in = _scale_reference(reference_points, src_valid_ratios)
+            output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
+                           src_padding_mask)
+            reference_points = self._refine(lid, output, reference_points)
+            if self.return_intermediate:
+                inter.append(output)
+                inter_refs.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_refs)
+        return output, reference_points
+
+
+class TemporalDeformableTransformerDecoder(DeformableTransformerDecoder):
+    """The TDTD decoder of TransVOD++: same layers, but box refinement is switched off on every
+    call (the reference resets ``self.bbox_embed = None`` inside the loop,
+    deformable_transformer_multi_plusplus.py:1055)."""
+
+    def _refine(self, lid, output, reference_points):
+        self.bbox_embed = None
+        return reference_points
+
+
+# ---- temporal query / memory layers -----------------------------------------------------------------
+class TemporalQueryEncoderLayer(nn.Module):
+    """TQE: self-attention over the current frame's queries, then cross-attention to the selected
+    reference-frame queries, then FFN (ref deformable_transformer_multi_plusplus.py:787-838)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_heads=8):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.cross_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    with_pos_embed = staticmethod(_add_pos)
+
+    def forward_ffn(self, tgt):
+        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(y))
+
+    def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
+        qk = _add_pos(query, query_pos)
+        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), query.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm2(query + self.dropout2(y))
+        y = self.cross_attn(_add_pos(tgt, query_pos).transpose(0, 1),
+                            _add_pos(ref_query, ref_query_pos).transpose(0, 1),
+                            ref_query.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm1(tgt + self.dropout1(y))
+        return self.forward_ffn(tgt)
+
+
+class TemporalQueryEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
+        out = query
+        for layer in self.layers:
+            out = layer(out, ref_query, query_pos, ref_query_pos)
+        return out
+
+
+class TemporalDeformableTransformerEncoderLayer(nn.Module):
+    """TDAM memory layer of TransVOD: the current frame attends to the reference frames' memories
+    with MSDA, one "level" per reference frame (ref deformable_transformer_multi_plusplus.py:853-901)."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", num_ref_frames=3, n_heads=8,
+                 n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, num_ref_frames, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    with_pos_embed = staticmethod(_add_pos)
+
+    def forward_ffn(self, tgt):
+        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(y))
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
+                src_padding_mask=None):
+        qk = _add_pos(tgt, query_pos)
+        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(y))
+        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                            frame_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(y))
+        return self.forward_ffn(tgt)
