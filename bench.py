@@ -1,0 +1,176 @@
+"""Headline benchmark: frames/s of TransVOD++ Late-Fusion inference at 800x1333 RGB-D on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[4], SURVEY.md 8d "config E"): one synthetic 32-frame RGB-D clip,
+frames [32,4,800,1333] ~ N(0,1) (seed 42), no padding, every frame gets an output with the other
+31 frames as its reference frames ("all-current" mode, models/clip_inference.py).  Weights are each
+module's own initialisation under seed 42 (no checkpoints exist offline).  The clip is FIXED and
+its frames are sharded in contiguous blocks over the N ranks (strong scaling): one rank per GPU,
+one RCCL all-gather of the per-frame reference query sets per step.  A step = the whole clip.
+Inputs are resident in HBM before the timed region.  Compute type fp32 throughout.
+
+The JSON line also carries
+  roofline     the MSDA forward kernel at the encoder geometry (N = frames per micro-batch,
+               Lq = S = 4200, L = 1): algorithmic bytes 4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per
+               launch over the mean launch time, measured with HIP events recorded on the launch
+               stream inside the timed steps; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
+  cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
+               the CPU oracle standing in for the two HIP operators - timed on a bounded sample
+               (a 2-frame clip at full resolution) on the box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd")
+for _p in (PKG, ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# per-frame algorithmic work of config E (all-current mode)
+BYTES_PER_FRAME = 4.333e9
+FLOPS_PER_FRAME = 343.3e9
+HBM_PEAK = 8.0e12
+FP32_MFMA_PEAK = 157.3e12
+
+
+def build(device, num_ref_frames):
+    from models import build_model
+    from models.config import transvodpp_args
+    torch.manual_seed(42)
+    model, _, _ = build_model(transvodpp_args("LateFusion", num_ref_frames=num_ref_frames, device=str(device)))
+    return model.to(device).eval()
+
+
+def cpu_baseline(height, width, threads, frames=2):
+    """The same host code on CPU tensors, the oracle as the MSDA / RoIAlign operator."""
+    from oracle import msda_oracle
+    import models.ops.functions.ms_deform_attn_func as f
+    from dfx import ops
+    from models.clip_inference import ClipRunner
+    torch.set_num_threads(threads)
+    msda_oracle.set_threads(threads)
+    saved = (f.MSDeformAttnFunction, ops.roi_align)
+
+    def roi_align(inp, rois, output_size, spatial_scale, sampling_ratio, aligned=True, channels_last=False):
+        size = output_size if isinstance(output_size, int) else output_size[0]
+        if channels_last:
+            out = msda_oracle.roi_align(inp.permute(0, 3, 1, 2).contiguous(), rois, size, spatial_scale,
+                                        sampling_ratio, aligned)
+            return out.flatten(2).transpose(1, 2).contiguous()
+        return msda_oracle.roi_align(inp, rois, size, spatial_scale, sampling_ratio, aligned)
+
+    f.MSDeformAttnFunction, ops.roi_align = msda_oracle.OracleMSDAFunction, roi_align
+    try:
+        model = build("cpu", frames - 1)
+        clip = torch.randn(frames, 4, height, width, generator=torch.Generator().manual_seed(42))
+        runner = ClipRunner(model, micro_batch=1)
+        t0 = time.perf_counter()
+        runner(clip)
+        dt = time.perf_counter() - t0
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"one {frames}-frame clip at {height}x{width}, all-current mode, {dt:.1f} s of CPU work, "
+                      "torch CPU ops + oracle/msda_oracle.c for MSDA and RoIAlign"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=32, help="clip length T (fixed across N)")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--micro-batch", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the operators have no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)          # RCCL on ROCm
+    assert a.frames % world == 0, "the clip must split evenly over the ranks"
+    per_rank = a.frames // world
+
+    from dfx import _lib, ops
+    from models.clip_inference import ClipRunner
+    _lib.load()                                                     # fail loudly without the HIP library
+    model = build(device, a.frames - 1)
+    clip = torch.randn(a.frames, 4, a.height, a.width, generator=torch.Generator().manual_seed(42))
+    mine = clip[rank * per_rank:(rank + 1) * per_rank].to(device)   # resident in HBM before timing
+    runner = ClipRunner(model, micro_batch=min(a.micro_batch, per_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        runner(mine)
+    barrier()
+    ops.PROFILE = []                                               # HIP events around encoder-shape MSDA launches
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        runner(mine)
+    barrier()
+    dt = time.perf_counter() - t0
+    events, ops.PROFILE = ops.PROFILE, None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        fps = a.frames * a.steps / dt
+        enc = [(e0.elapsed_time(e1) * 1e-3, nbytes) for (e0, e1, nbytes, lq, s) in events if lq == s]
+        roof = None
+        if enc:
+            mean_t = sum(x for x, _ in enc) / len(enc)
+            nbytes = enc[0][1]
+            roof = {"bound": "hbm", "kernel": "msda_fused_taps<1,2> (encoder / late-fusion geometry)",
+                    "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": round(nbytes / mean_t / HBM_PEAK, 4), "traffic": None,
+                    "launches": len(enc), "bytes_per_launch": nbytes, "avg_launch_us": round(mean_t * 1e6, 2)}
+        line = {
+            "metric": "frames/sec at 800x1333 RGB-D, TransVOD++ Late-Fusion", "value": round(fps, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TransVOD++ LateFusion, {a.frames}-frame {a.height}x{a.width} RGB-D clip, "
+                                   f"all-current mode (R={a.frames - 1}), L=1 DC5 (S=4200), 300 queries, 3 classes",
+                       "frames_per_gpu": per_rank, "micro_batch": min(a.micro_batch, per_rank),
+                       "parallelism": f"frame-shard x{world} + 1 all-gather/clip"},
+            "roofline": roof,
+            "e2e": {"hbm_frac": round(fps / world * BYTES_PER_FRAME / HBM_PEAK, 4),
+                    "fp32_mfma_frac": round(fps / world * FLOPS_PER_FRAME / FP32_MFMA_PEAK, 4),
+                    "bytes_per_frame": BYTES_PER_FRAME, "flops_per_frame": FLOPS_PER_FRAME},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.height, a.width, min(a.cpu_threads, os.cpu_count() or 1))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,10 @@ from . import _lib
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 
+# Measurement hook (bench.py): when set to a list, every fused MSDA launch is bracketed by two
+# HIP events recorded on the launch stream and (start, end, algorithmic_bytes, Lq, S) is appended.
+PROFILE = None
+
 
 def _require(cond, msg):
     if not cond:
@@ -120,12 +124,19 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     _require(reference_points.dtype == torch.float32 and reference_points.shape[0] == N, "bad reference_points")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     base = qproj.data_ptr()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(value.device))
     with torch.cuda.device(value.device):
         rc = lib.dfx_msda_fused_forward_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             reference_points.data_ptr(), ref_dim, Lr,
             base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
             N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
+    if prof is not None:
+        e1.record(torch.cuda.current_stream(value.device))
+        prof.append((e0, e1, 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D), Lq, S))
     _lib.check(rc, "msda_fused_forward")
     return out
 

@@ -1,0 +1,110 @@
+"""Clip inference for TransVOD++ with every frame of the clip as "current" frame, optionally with
+the clip's frames spread over several GPUs (one process per GPU, RCCL over xGMI).
+
+The reference forward consumes a clip of T = 1+R frames and emits ONE output, for frame 0
+(/root/reference/models/deformable_transformer_multi_plusplus.py:404-406,601).  Running it T times
+with each frame in front would redo the whole spatial stage T times.  This runner computes, for
+every frame t, exactly what the reference forward would output for the clip re-ordered as
+[t, other frames in clip order] - but each frame's spatial stage (backbones, Late Fusion, encoder,
+decoder) and its two query/RoI fusion passes run ONCE:
+
+  1. spatial stage on the rank's own frames (micro-batched);
+  2. ``frame_stage``: class logits + both RoI-fused query sets ("cur": plain memory, "ref":
+     memory + positional embedding - the reference treats the two roles differently);
+  3. one all-gather of the "ref" query sets [Q,256] and class logits [Q,classes] of every frame
+     (the only inter-GPU exchange: ~0.31 MB per frame);
+  4. ``temporal_stage`` for each owned frame against all other frames' gathered queries, then the
+     final temporal heads.
+
+Frames are independent until step 3 (frozen / eval-mode norms, per-sample attention), so the
+clip shards by contiguous blocks of frames with weights replicated.
+"""
+import torch
+import torch.distributed as dist
+
+from util.misc import NestedTensor
+
+from .detector_common import apply_box_head
+
+
+class ClipRunner:
+    def __init__(self, model, micro_batch=4, group=None):
+        """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode."""
+        self.model = model
+        self.micro_batch = micro_batch
+        self.group = group
+
+    # ---- steps 1+2 for a block of frames -------------------------------------------------------
+    @torch.no_grad()
+    def frames_forward(self, frames, mask=None):
+        """frames [F,4|3,H,W] (this rank's frames) -> dict of per-frame tensors."""
+        m, tr = self.model, self.model.transformer
+        F_, _, H, W = frames.shape
+        if mask is None:
+            mask = torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device)
+        whwh = torch.as_tensor((W, H, W, H), dtype=torch.long, device=frames.device).repeat(1, m.num_queries, 1)
+        keep = {k: [] for k in ("cur", "ref", "logits", "ref_last", "memory")}
+        meta = None
+        for s in range(0, F_, self.micro_batch):
+            sl = slice(s, min(F_, s + self.micro_batch))
+            srcs, masks, pos, d_srcs, d_masks, d_pos, rgbd = m._encode_inputs(NestedTensor(frames[sl], mask[sl]))
+            st = tr._spatial_stage(srcs, masks, pos, d_srcs, d_masks, d_pos, m.query_embed.weight, rgbd)
+            fs = tr.frame_stage(st["hs"][-1], st["inter_references"][-1], st["memory"],
+                                st["lvl_pos_embed_flatten"], st["last_hw"], whwh, m.class_embed[-1],
+                                m.bbox_embed[-1], roles=("cur", "ref"))
+            keep["cur"].append(fs["cur"])
+            keep["ref"].append(fs["ref"])
+            keep["logits"].append(fs["logits"])
+            keep["ref_last"].append(st["inter_references"][-1])
+            keep["memory"].append(st["memory"])
+            meta = (st["spatial_shapes"], st["level_start_index"])
+            keep.setdefault("valid_ratios", []).append(st["valid_ratios"])
+        out = {k: torch.cat(v, 0) for k, v in keep.items()}
+        out["spatial_shapes"], out["level_start_index"] = meta
+        return out
+
+    # ---- step 3 ---------------------------------------------------------------------------------
+    def exchange(self, ref, logits):
+        """all-gather the per-frame reference query sets and logits over the clip's ranks.
+        ref [F,Q,C], logits [F,Q,K] -> ([T,Q,C], [T,Q,K]) in clip order (rank-major)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return ref, logits
+        world = dist.get_world_size(self.group)
+        F_, Q, C = ref.shape
+        K = logits.shape[-1]
+        packed = torch.cat([ref, logits], dim=-1).contiguous()            # one message per rank
+        gathered = torch.empty((world * F_, Q, C + K), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        return gathered[..., :C].contiguous(), gathered[..., C:].contiguous()
+
+    # ---- step 4 ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def temporal_forward(self, local, all_ref, all_logits, first_frame):
+        """Outputs for each local frame t (global index first_frame + i) as the current frame."""
+        m, tr = self.model, self.model.transformer
+        T, Q, C = all_ref.shape
+        F_ = local["cur"].shape[0]
+        logits_out, boxes_out, picks_out = [], [], []
+        for i in range(F_):
+            t = first_frame + i
+            others = [j for j in range(T) if j != t]
+            idx = torch.as_tensor(others, device=all_ref.device)
+            ref_hs = all_ref.index_select(0, idx).reshape(1, (T - 1) * Q, C)
+            ref_lg = all_logits.index_select(0, idx).reshape(1, (T - 1) * Q, -1)
+            final_hs, final_refs, _, picks = tr.temporal_stage(
+                local["cur"][i:i + 1], local["ref_last"][i:i + 1], local["memory"][i:i + 1], ref_hs, ref_lg,
+                local["spatial_shapes"], local["level_start_index"], local["valid_ratios"][i:i + 1],
+                m.temp_class_embed_list, m.temp_bbox_embed_list)
+            logits_out.append(m.temp_class_embed_list[2](final_hs))
+            boxes_out.append(apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs))
+            picks_out.append(picks)
+        return {"pred_logits": torch.cat(logits_out, 0), "pred_boxes": torch.cat(boxes_out, 0), "topk": picks_out}
+
+    @torch.no_grad()
+    def __call__(self, frames, mask=None):
+        """frames: this rank's contiguous block of the clip, [T/world, C, H, W].
+        -> {"pred_logits" [F,Q,classes], "pred_boxes" [F,Q,4]} for the rank's frames."""
+        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        local = self.frames_forward(frames, mask)
+        all_ref, all_logits = self.exchange(local["ref"], local["logits"])
+        return self.temporal_forward(local, all_ref, all_logits, first_frame=rank * frames.shape[0])

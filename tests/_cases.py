@@ -15,19 +15,22 @@ from types import SimpleNamespace
 
 import torch
 
-from tests._param_fill import fill_params_by_name
+from tests._param_fill import fill_params_by_name as _fill_by_name
+
+
+_DEVICE = "cpu"   # set by run_cases; inputs are always DRAWN on the CPU generator, then moved
 
 
 def rnd(seed, *shape, scale=1.0):
-    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(_DEVICE)
 
 
 def urnd(seed, *shape):
-    return torch.rand(*shape, generator=torch.Generator().manual_seed(seed))
+    return torch.rand(*shape, generator=torch.Generator().manual_seed(seed)).to(_DEVICE)
 
 
 def levels(shape_list):
-    shapes = torch.as_tensor(shape_list, dtype=torch.long)
+    shapes = torch.as_tensor(shape_list, dtype=torch.long).to(_DEVICE)
     lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
     return shapes, lsi, int(shapes.prod(1).sum())
 
@@ -41,15 +44,20 @@ def pad_masks(seed, n, h, w):
         vw = int(torch.randint(max(1, w * 2 // 3), w + 1, (1,), generator=g))
         m[i, :vh, :vw] = False
     m[0] = False
-    return m
+    return m.to(_DEVICE)
 
 
 
-def run_cases(ns):
+def run_cases(ns, device="cpu"):
     MSDeformAttn, ts, tpp, tm, RCNNHead = ns.MSDeformAttn, ns.ts, ns.tpp, ns.tm, ns.RCNNHead
     dfb, dcf, PositionEmbeddingSine = ns.dfb, ns.dcf, ns.PositionEmbeddingSine
     NestedTensor, inverse_sigmoid = ns.NestedTensor, ns.inverse_sigmoid
+    global _DEVICE
+    _DEVICE = device
     blobs = {}
+
+    def fill_params_by_name(module, seed=0, prefix=""):   # fill on the CPU, then move
+        return _fill_by_name(module, seed=seed, prefix=prefix).to(device)
 
     def put(case, **tensors):
         for k, v in tensors.items():
@@ -68,13 +76,13 @@ def run_cases(ns):
 
     # ---- a5/a9/TQE/a12: single layers -------------------------------------------------------------------
     shapes, lsi, S = levels([(6, 8)])
-    grid = ts.DeformableTransformer.get_reference_points(shapes, torch.ones(2, 1, 2), "cpu")
+    grid = ts.DeformableTransformer.get_reference_points(shapes, torch.ones(2, 1, 2, device=device), device)
     src, pos = rnd(10, 2, S, 256), rnd(11, 2, S, 256)
     layer = fill_params_by_name(ts.DeformableTransformerEncoderLayer(256, 1024, 0.1, "relu", 1, 8, 4).eval(), seed=2)
     put("enc_layer", out=layer(src, pos, grid, shapes, lsi, None))
 
     tgt, qpos = rnd(12, 2, 21, 256), rnd(13, 2, 21, 256)
-    ref4 = urnd(14, 2, 21, 1, 4) * torch.tensor([1, 1, 0.4, 0.4])
+    ref4 = urnd(14, 2, 21, 1, 4) * torch.tensor([1, 1, 0.4, 0.4], device=device)
     layer = fill_params_by_name(ts.DeformableTransformerDecoderLayer(256, 1024, 0.1, "relu", 1, 8, 4).eval(), seed=3)
     put("dec_layer", out=layer(tgt, qpos, ref4, src, shapes, lsi, None))
 
@@ -108,8 +116,8 @@ def run_cases(ns):
 
     # ---- a17: positional encoding, inverse_sigmoid ------------------------------------------------------
     m = pad_masks(23, 2, 7, 9)
-    put("pos_sine", out=pe(NestedTensor(torch.zeros(2, 1, 7, 9), m)))
-    x = torch.cat([urnd(24, 50), torch.tensor([0.0, 1.0, -0.2, 1.3, 1e-7, 1 - 1e-7])])
+    put("pos_sine", out=pe(NestedTensor(torch.zeros(2, 1, 7, 9, device=device), m)))
+    x = torch.cat([urnd(24, 50), torch.tensor([0.0, 1.0, -0.2, 1.3, 1e-7, 1 - 1e-7], device=device)])
     put("inverse_sigmoid", out=inverse_sigmoid(x))
 
     # ---- a15: DFormer depth backbone --------------------------------------------------------------------
