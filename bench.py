@@ -36,6 +36,10 @@ for _p in (PKG, ROOT):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# fp32 means fp32: no reduced-precision matmul / convolution modes
+torch.backends.cuda.matmul.allow_tf32 = False
+torch.backends.cudnn.allow_tf32 = False
+
 # per-frame algorithmic work of config E (all-current mode)
 BYTES_PER_FRAME = 4.333e9
 FLOPS_PER_FRAME = 343.3e9

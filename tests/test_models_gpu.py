@@ -18,7 +18,7 @@ def golden(golden_dir):
 
 def test_every_block_matches_the_reference_on_gpu(golden):
     from dfx import _lib
-    from tests._cases import run_cases
+    from tests._cases import pad_masks, run_cases
     from tests.test_models_golden import my_namespace
     _lib.load()
     with torch.no_grad():
@@ -30,7 +30,13 @@ def test_every_block_matches_the_reference_on_gpu(golden):
         if ref.dtype == torch.bool:
             assert torch.equal(out, ref), key
             continue
-        err = (out.float() - ref.float()).abs().max().item()
+        diff = (out.float() - ref.float()).abs()
+        if key in ("dformer.pos", "pos_sine.out"):
+            # fully padded rows/columns normalise by eps: sin/cos of ~1e6, where CPU and GPU range
+            # reduction legitimately differ; only positions of valid pixels are meaningful
+            valid = ~(torch.from_numpy(golden["dformer.feat_mask"]) if key == "dformer.pos" else pad_masks(23, 2, 7, 9).cpu())
+            diff = diff * valid[:, None].to(diff.dtype)
+        err = diff.max().item()
         assert err < 1e-3, f"{key}: max abs err {err:.3e} (north-star bound 1e-3)"
         assert err < 2e-4, f"{key}: max abs err {err:.3e}"
 
