@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="clip length T (fixed across N)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
-    ap.add_argument("--micro-batch", type=int, default=4)
+    ap.add_argument("--micro-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     a = ap.parse_args()

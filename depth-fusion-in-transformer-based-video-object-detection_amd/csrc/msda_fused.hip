@@ -12,9 +12,11 @@
 //
 // `Lr` is the number of reference-point levels.  Lr == L is the normal module.  Lr > L (with
 // L == 1) is the TransVOD temporal decoder: the module there builds a location tensor
-// [N,Lq,M,Lr,P,2] and the CUDA op reads it flat as [N,Lq,M,1,P,2] (SURVEY.md 0.6,
+// [1,Lq,M,Lr,P,2] and the CUDA op reads it flat as [1,Lq,M,1,P,2] (SURVEY.md 0.6,
 // ms_deform_attn_cuda.cu:45-48); row j of that flat view is (query j/(Lr*M), head (j/Lr)%M,
-// level j%Lr) of the tensor the module built, which is what `src_row` below reproduces.
+// level j%Lr) of the tensor the module built.  The reference only ever does this with N == 1;
+// for N > 1 this kernel applies the same rule to every batch element on its own (N independent
+// reference calls), which is what batching the temporal stage over frames needs.
 #include "dfx_common.h"
 #include "msda_tap.h"
 
@@ -84,13 +86,20 @@ __global__ __launch_bounds__(256) void msda_fused_taps(const float *__restrict__
                     if (k == l) mine = (p == 0) ? ex : (p == 1) ? ey : (p == 2) ? ez : ew;
                 }
                 const float a = mine / sum;
-                // ---- location: which (query, head, reference level) flat row i*L+l of the location
-                //      tensor [N,Lq,M,Lr,P,2] is (identity when Lr == L)
-                const long j = ((long)qi * 8 + hm) * LT + l;
-                const int r = (int)(j % Lr);
-                const int ms = (int)((j / Lr) & 7);
-                const long qs = j / ((long)Lr * 8);
-                const int lo = (Lr == LT) ? r : 0;
+                // ---- location: which (query, head, reference level) of the tensor the module builds,
+                //      [Lq,M,Lr,P,2] per batch element, flat row (q*M+m)*L+l of the op's view is
+                //      (identity when Lr == L; otherwise L == 1 and the op reads the prefix of the
+                //      batch element's tensor flat, see the file header)
+                int r = l, ms = hm, lo = l;
+                long qs = qi;
+                if (Lr != LT) {
+                    const int b = qi / Lq;
+                    const long j = ((long)(qi - b * Lq) * 8 + hm) * LT + l;
+                    r = (int)(j % Lr);
+                    ms = (int)((j / Lr) & 7);
+                    qs = (long)b * Lq + j / ((long)Lr * 8);
+                    lo = 0;
+                }
                 const float *rp = ref + (qs * Lr + r) * REFDIM;
                 const float2 o2 = *reinterpret_cast<const float2 *>(off + qs * off_stride + ((ms * LT + lo) * 4 + p) * 2);
                 int H = Hs[0], W = Ws[0], R = Rs[0];

@@ -168,3 +168,23 @@ def roi_align(inp, rois, output_size, spatial_scale, sampling_ratio, aligned=Tru
                 int(sampling_ratio), int(bool(aligned)), out.data_ptr(), _stream(inp.device))
     _lib.check(rc, "roi_align")
     return out
+
+
+def bias_act_(x, bias, residual=None, relu=True):
+    """In place on ``x`` [N,C,*spatial] (contiguous NCHW): x = relu?(x + bias[c] (+ residual)).
+    One HBM pass for what the reference runs as FrozenBatchNorm2d (after folding its scale into
+    the convolution weights) + residual add + ReLU (include/dfx_fused.h)."""
+    lib = _lib.load()
+    named = [("x", x), ("bias", bias)] + ([("residual", residual)] if residual is not None else [])
+    _check_inputs(named)
+    _require(x.dtype == torch.float32 and bias.dtype == torch.float32, "bias_act_ is implemented for float32")
+    N, C = x.shape[0], x.shape[1]
+    _require(bias.numel() == C, "bias must have one entry per channel")
+    if residual is not None:
+        _require(residual.shape == x.shape and residual.dtype == x.dtype, "residual must match x")
+    hw = x.numel() // max(N * C, 1)
+    with torch.cuda.device(x.device):
+        rc = lib.dfx_bias_act_nchw_f32(x.data_ptr(), bias.data_ptr(), 0 if residual is None else residual.data_ptr(),
+                                       x.data_ptr(), N, C, hw, int(bool(relu)), _stream(x.device))
+    _lib.check(rc, "bias_act_")
+    return x

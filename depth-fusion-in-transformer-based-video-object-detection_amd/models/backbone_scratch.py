@@ -70,17 +70,21 @@ class FusionBackboneBase(nn.Module):
         self.return_layer_no = [2, 3, 4] if return_interm_layers else [4]
         self.strides = [8, 16, 32] if return_interm_layers else [32]
         self.return_layers = {f"layer{i}": str(k) for k, i in enumerate(self.return_layer_no)}
+        # set by models.fused.enable_fused_inference(): GPU-only inference path with frozen BN folded
+        # into the convolutions and fused bias/residual/ReLU epilogues
+        self.fused_inference = False
 
     def forward(self, tensor_list: NestedTensor):
         x = tensor_list.tensors[:, :3]
         m = tensor_list.mask
         assert m is not None, "Mask should not be None"
         body = self.body
-        x = body.maxpool(body.relu(body.bn1(body.conv1(x))))
+        fused = self.fused_inference and not torch.is_grad_enabled()
+        x = body.stem(x, fused)
         out: Dict[str, NestedTensor] = {}
         wanted = set(self.return_layers.values()) if self.return_interm_layers else set()
         for key, stage in (("0", body.layer1), ("1", body.layer2), ("2", body.layer3), ("3", body.layer4)):
-            x = stage(x)
+            x = body.run_stage(stage, x, fused)
             if key == "3":
                 # the last stage always reports; under key "3" only if such a key was requested
                 out["3" if key in wanted else "0"] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))

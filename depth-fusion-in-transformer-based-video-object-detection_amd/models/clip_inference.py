@@ -25,14 +25,19 @@ import torch.distributed as dist
 from util.misc import NestedTensor
 
 from .detector_common import apply_box_head
+from .fused import enable_fused_inference
 
 
 class ClipRunner:
-    def __init__(self, model, micro_batch=4, group=None):
-        """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode."""
+    def __init__(self, model, micro_batch=4, group=None, fused=None):
+        """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode.
+        fused: use the GPU-only fused inference routes (models/fused.py); default = model is on a GPU."""
         self.model = model
         self.micro_batch = micro_batch
         self.group = group
+        if fused is None:
+            fused = next(model.parameters()).is_cuda
+        enable_fused_inference(model, fused)
 
     # ---- steps 1+2 for a block of frames -------------------------------------------------------
     @torch.no_grad()
@@ -80,25 +85,20 @@ class ClipRunner:
     # ---- step 4 ---------------------------------------------------------------------------------
     @torch.no_grad()
     def temporal_forward(self, local, all_ref, all_logits, first_frame):
-        """Outputs for each local frame t (global index first_frame + i) as the current frame."""
+        """Outputs for each local frame t (global index first_frame + i) as the current frame, all
+        local frames in one batched pass."""
         m, tr = self.model, self.model.transformer
-        T, Q, C = all_ref.shape
+        T = all_ref.shape[0]
         F_ = local["cur"].shape[0]
-        logits_out, boxes_out, picks_out = [], [], []
-        for i in range(F_):
-            t = first_frame + i
-            others = [j for j in range(T) if j != t]
-            idx = torch.as_tensor(others, device=all_ref.device)
-            ref_hs = all_ref.index_select(0, idx).reshape(1, (T - 1) * Q, C)
-            ref_lg = all_logits.index_select(0, idx).reshape(1, (T - 1) * Q, -1)
-            final_hs, final_refs, _, picks = tr.temporal_stage(
-                local["cur"][i:i + 1], local["ref_last"][i:i + 1], local["memory"][i:i + 1], ref_hs, ref_lg,
-                local["spatial_shapes"], local["level_start_index"], local["valid_ratios"][i:i + 1],
-                m.temp_class_embed_list, m.temp_bbox_embed_list)
-            logits_out.append(m.temp_class_embed_list[2](final_hs))
-            boxes_out.append(apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs))
-            picks_out.append(picks)
-        return {"pred_logits": torch.cat(logits_out, 0), "pred_boxes": torch.cat(boxes_out, 0), "topk": picks_out}
+        dev = all_ref.device
+        others = torch.as_tensor([[j for j in range(T) if j != first_frame + i] for i in range(F_)],
+                                 dtype=torch.long, device=dev)                     # [F, T-1], clip order
+        final_hs, final_refs, _, picks = tr.temporal_stage(
+            local["cur"], local["ref_last"], local["memory"], all_ref, all_logits, others,
+            local["spatial_shapes"], local["level_start_index"], local["valid_ratios"],
+            m.temp_class_embed_list, m.temp_bbox_embed_list)
+        return {"pred_logits": m.temp_class_embed_list[2](final_hs),
+                "pred_boxes": apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs), "topk": picks}
 
     @torch.no_grad()
     def __call__(self, frames, mask=None):

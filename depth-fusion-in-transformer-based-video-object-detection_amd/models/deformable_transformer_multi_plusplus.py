@@ -11,7 +11,7 @@ shared with the single-frame model (``SpatialTransformerBase``).  The temporal s
               ``temporal_query_layer{i}`` (TQE) -> ``temporal_decoder{i}`` (TDTD) on the current memory ]
 
 is written here as two functions, ``frame_stage`` and ``temporal_stage``, so that a clip whose
-frames are spread over several GPUs can exchange just the per-frame results (parallel/clip_shard.py).
+frames are spread over several GPUs can exchange just the per-frame results (models/clip_inference.py).
 ``forward`` composes them exactly as the reference does for one clip on one device.
 
 Quirks of the reference that are kept (SURVEY.md sections 0.6 and 8a, row a11): the temporal
@@ -88,47 +88,49 @@ class DeformableTransformer(SpatialTransformerBase):
     # ------------------------------------------------------------------------------------------
     def frame_stage(self, hs_last, ref_last, memory, pos_embed, hw, imgs_whwh, class_embed, bbox_embed,
                     roles=("cur", "ref")):
-        """Per-frame half of the temporal stage for F frames (any subset of a clip).
+        """Per-frame half of the temporal stage for F frames (any subset of a clip), batched.
 
         hs_last [F,Q,C] last decoder layer output, ref_last [F,Q,4] its reference boxes,
         memory [F,S,C], pos_embed [F,S,C] (level-embedded positional embedding), hw = (h, w).
         Returns a dict with, per frame:
           logits [F,Q,classes]; boxes [F,Q,4] (sigmoid, cxcywh)
-          "cur": queries fused with RoI features of the plain memory          [F,Q,C]
+          "cur": queries fused with RoI features of the plain memory              [F,Q,C]
           "ref": queries fused with RoI features of memory + positional embedding [F,Q,C]
         (ref :450-518; a frame needs "cur" when it is the current frame and "ref" when it serves
-        as a reference frame.)"""
+        as a reference frame.  The reference runs RoIAlign and the fusion head once per frame; the
+        head's self-attention is per batch element, so all frames go through in one call.)"""
         h, w = hw
         F_, Q, C = hs_last.shape
         logits = class_embed(hs_last)
         boxes = (bbox_embed(hs_last) + inverse_sigmoid(ref_last)).sigmoid()
         xyxy = box_ops.box_cxcywh_to_xyxy(boxes) * imgs_whwh                      # image pixels
+        rois = bbox2roi([xyxy[f] for f in range(F_)])                             # [F*Q,5], image index = frame
         out = dict(logits=logits, boxes=boxes)
         roi = self.temporal_roi_layers1[0]
         head = self.dynamic_layer_for_current_query1
         for role in roles:
             mem = memory if role == "cur" else memory + pos_embed
-            fused = []
-            for f in range(F_):                     # the head's self-attention is per frame
-                rois = bbox2roi([xyxy[f]])
-                fmap = mem[f:f + 1].permute(0, 2, 1).unsqueeze(-1).view(1, C, h, w)   # channels-last view
-                feats = roi(fmap, rois)
-                fused.append(head(feats, hs_last[f:f + 1]))
-            out[role] = torch.cat(fused, 0)
+            fmap = mem.permute(0, 2, 1).unsqueeze(-1).view(F_, C, h, w)           # channels-last view, no copy
+            out[role] = head(roi(fmap, rois), hs_last).view(F_, Q, C)
         return out
 
-    def temporal_stage(self, cur_hs, cur_reference_out, cur_memory, ref_hs_concat, ref_logits_concat,
+    def temporal_stage(self, cur_hs, cur_reference_out, cur_memory, ref_pool, logit_pool, others,
                        spatial_shapes, level_start_index, valid_ratio_cur, temp_class_embed_list,
                        temp_bbox_embed_list):
-        """Per-clip half for ONE current frame (ref :525-601).
+        """Per-clip half for F current frames at once (ref :525-601 runs it for one).
 
-        cur_hs [1,Q,C] ("cur" fused queries), cur_reference_out [1,Q,4], cur_memory [1,S,C],
-        ref_hs_concat [1,R*Q,C] ("ref" fused queries of the R reference frames, clip order),
-        ref_logits_concat [1,R*Q,classes], valid_ratio_cur [1,L,2] of the current frame.
-        -> final_hs [1,Q,C], final_references [1,Q,4], aux outputs, top-k indices."""
-        R = ref_hs_concat.shape[1] // cur_hs.shape[1]
-        score = ref_logits_concat.sigmoid()[:, :, 1]
-        ratios = valid_ratio_cur[:, :1].expand(1, R, 2)        # [1,R,2]: R "levels" of reference boxes
+        cur_hs [F,Q,C] ("cur" fused queries), cur_reference_out [F,Q,4], cur_memory [F,S,C];
+        ref_pool [T',Q,C] / logit_pool [T',Q,classes]: "ref" fused queries and class logits of the
+        frames that can serve as reference frames; others [F,R] (long): for each current frame the
+        R rows of the pools that are ITS reference frames, in clip order; valid_ratio_cur [F,L,2].
+        -> final_hs [F,Q,C], final_references [F,Q,4], aux outputs, top-k indices [F,k*R] (indices
+        into the frame's own concatenation of R*Q reference queries, like the reference's)."""
+        F_, Q, C = cur_hs.shape
+        R = others.shape[1]
+        # class-1 score of every reference query, per current frame: [F, R*Q]
+        score = logit_pool.sigmoid()[:, :, 1][others].reshape(F_, R * Q)
+        flat_pool = ref_pool.reshape(-1, C)
+        ratios = valid_ratio_cur[:, :1].expand(F_, R, 2)       # R "levels" of reference boxes
         shapes1, lsi1 = spatial_shapes[0:1], level_start_index[0:1]
         for attr in ("_dfx_host", "_dfx_tokens"):
             if hasattr(spatial_shapes, attr) and spatial_shapes.shape[0] == 1:
@@ -136,9 +138,10 @@ class DeformableTransformer(SpatialTransformerBase):
         aux, picks = [], []
         final_hs, final_refs = cur_hs, cur_reference_out
         for i, k in enumerate(TOPK_PER_REF):
-            idx = torch.topk(score, k * R, dim=1)[1]
+            idx = torch.topk(score, k * R, dim=1)[1]                               # [F,kR] in [0, R*Q)
             picks.append(idx)
-            selected = torch.gather(ref_hs_concat, 1, idx.unsqueeze(-1).repeat(1, 1, ref_hs_concat.shape[-1]))
+            rows = torch.gather(others, 1, idx // Q) * Q + idx % Q                 # rows of the flat pool
+            selected = flat_pool[rows.reshape(-1)].view(F_, k * R, C)
             cur_hs = getattr(self, f"temporal_query_layer{i + 1}")(cur_hs, selected)
             cur_hs, refs = getattr(self, f"temporal_decoder{i + 1}")(
                 cur_hs, cur_reference_out, cur_memory, shapes1, lsi1, ratios, None, None)
@@ -175,11 +178,9 @@ class DeformableTransformer(SpatialTransformerBase):
                                   s["last_hw"], whwh, class_embed, cur_bbox_embed, roles=("cur",))
         fs_ref = self.frame_stage(hs[-1][1:], inter_refs[-1][1:], memory[1:], s["lvl_pos_embed_flatten"][1:],
                                   s["last_hw"], whwh, class_embed, cur_bbox_embed, roles=("ref",))
-        Q, C = hs.shape[2], hs.shape[3]
-        ref_hs_concat = fs_ref["ref"].reshape(1, self.num_ref_frames * Q, C)
-        ref_logits_concat = fs_ref["logits"].reshape(1, self.num_ref_frames * Q, -1)
+        others = torch.arange(self.num_ref_frames, device=memory.device).view(1, -1)
         final_hs, final_refs, aux, _ = self.temporal_stage(
-            fs_cur["cur"], inter_refs[-1][:1], memory[:1], ref_hs_concat, ref_logits_concat,
+            fs_cur["cur"], inter_refs[-1][:1], memory[:1], fs_ref["ref"], fs_ref["logits"], others,
             s["spatial_shapes"], s["level_start_index"], s["valid_ratios"][:1], temp_class_embed_list,
             temp_bbox_embed_list)
         out = {"aux_outputs": aux}

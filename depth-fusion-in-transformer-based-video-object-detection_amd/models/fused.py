@@ -1,0 +1,17 @@
+"""Switch for the GPU-only fused inference routes of the host modules.
+
+Default module behaviour is the reference's op-by-op formulation (works on any device through
+PyTorch).  ``enable_fused_inference(model)`` turns on, for every module that has one, the route
+that runs on the hand-written gfx950 kernels (dfx.ops): folded frozen-BN + fused epilogues in the
+ResNet, ... These routes have no CPU implementation and raise on CPU tensors; the MSDA operator
+itself is always on the HIP kernels, fused route or not.
+"""
+
+
+def enable_fused_inference(model, enabled=True):
+    n = 0
+    for mod in model.modules():
+        if hasattr(mod, "fused_inference"):
+            mod.fused_inference = enabled
+            n += 1
+    return n

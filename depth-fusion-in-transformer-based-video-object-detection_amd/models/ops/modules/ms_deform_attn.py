@@ -116,6 +116,15 @@ class MSDeformAttn(nn.Module):
         else:
             locations = reference_points[:, :, None, :, None, :2] \
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
-        sampled = _func.MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                                   locations.contiguous(), weights, self.im2col_step)
+        locations = locations.contiguous()
+        if reference_points.shape[2] != L and N > 1:
+            # flat read of an over-long location tensor (TransVOD temporal decoder): the
+            # reference only does this with N == 1; each batch element follows that rule on its own
+            sampled = torch.cat([_func.MSDeformAttnFunction.apply(
+                value[b:b + 1].contiguous(), input_spatial_shapes, input_level_start_index,
+                locations[b:b + 1].contiguous(), weights[b:b + 1].contiguous(), self.im2col_step)
+                for b in range(N)], 0)
+        else:
+            sampled = _func.MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                       locations, weights, self.im2col_step)
         return self.output_proj(sampled)

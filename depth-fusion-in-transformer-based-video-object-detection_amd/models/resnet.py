@@ -9,7 +9,24 @@ torchvision itself is third-party and absent from /root/reference: PARITY UNPINN
 architecture; numerics are plain conv2d and pinned by torch.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
+
+from dfx import ops as _ops
+
+
+def _fold(conv, bn):
+    """Conv weight with the frozen-BN scale folded in, and the remaining per-channel shift."""
+    scale, shift = bn.scale_shift()
+    return (conv.weight.detach() * scale.reshape(-1, 1, 1, 1)).contiguous(), shift.detach().contiguous()
+
+
+def _versions(*mods):
+    out = []
+    for m in mods:
+        for t in list(m.parameters(recurse=False)) + list(m.buffers(recurse=False)):
+            out.append((t.data_ptr(), t._version))
+    return tuple(out)
 
 
 class Bottleneck(nn.Module):
@@ -25,6 +42,30 @@ class Bottleneck(nn.Module):
         self.bn3 = norm_layer(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        self._folded = None
+
+    def _folded_params(self):
+        mods = [self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.bn3]
+        if self.downsample is not None:
+            mods += [self.downsample[0], self.downsample[1]]
+        key = _versions(*mods)
+        if self._folded is None or self._folded[0] != key:
+            f = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]
+            f.append(_fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None)
+            self._folded = (key, f)
+        return self._folded[1]
+
+    def forward_fused(self, x):
+        """Inference on the GPU: frozen BN folded into the convolutions, bias + (residual) + ReLU in
+        one in-place pass (dfx.ops.bias_act_).  No CPU route."""
+        (w1, b1), (w2, b2), (w3, b3), down = self._folded_params()
+        c2 = self.conv2
+        out = _ops.bias_act_(F.conv2d(x, w1), b1, relu=True)
+        out = _ops.bias_act_(F.conv2d(out, w2, None, c2.stride, c2.padding, c2.dilation), b2, relu=True)
+        out = F.conv2d(out, w3)
+        if down is not None:
+            x = _ops.bias_act_(F.conv2d(x, down[0], None, self.downsample[0].stride), down[1], relu=False)
+        return _ops.bias_act_(out, b3, residual=x, relu=True)
 
     def forward(self, x):
         out = self.relu(self.bn1(self.conv1(x)))
@@ -65,6 +106,22 @@ class ResNet50(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes, 1, self.dilation, None, norm_layer))
         return nn.Sequential(*layers)
 
+    def stem(self, x, fused=False):
+        if not fused:
+            return self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        key = _versions(self.conv1, self.bn1)
+        if getattr(self, "_stem_folded", None) is None or self._stem_folded[0] != key:
+            self._stem_folded = (key, _fold(self.conv1, self.bn1))
+        w, b = self._stem_folded[1]
+        return self.maxpool(_ops.bias_act_(F.conv2d(x, w, None, 2, 3), b, relu=True))
+
+    def run_stage(self, stage, x, fused=False):
+        if not fused:
+            return stage(x)
+        for block in stage:
+            x = block.forward_fused(x)
+        return x
+
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.stem(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))

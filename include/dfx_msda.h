@@ -24,9 +24,9 @@
  *     default stream) and returns; no allocation, no synchronisation, no global
  *     state, re-entrant;
  *   - the caller owns every buffer; outputs are fully overwritten by forward;
- *     backward ACCUMULATES into grad_value and overwrites the flat prefix of
- *     grad_loc / grad_aw, so the caller zero-fills all three first (the
- *     reference allocates them with zeros_like, ms_deform_attn_cuda.cu:116-118);
+ *     backward ACCUMULATES (atomic adds) into grad_value, grad_loc and grad_aw,
+ *     so the caller zero-fills all three first (the reference allocates them
+ *     with zeros_like, ms_deform_attn_cuda.cu:116-118);
  *   - return value: 0 on success, a negative DFX_E* code otherwise; no C++
  *     exception ever crosses the boundary; dfx_last_error() gives the text.
  */
@@ -94,7 +94,9 @@ int dfx_msda_backward_f64(const double *value, const int64_t *shapes, const int6
  *          concatenated [offsets | logits] row
  *   ref    [N,Lq,Lr,ref_dim]; Lr == L normally.  Lr > L reproduces the flat
  *          read of the TransVOD temporal decoder: the
- *          virtual location tensor is [N,Lq,M,Lr,P,2] read flat with L levels.
+ *          virtual location tensor [Lq,M,Lr,P,2] of EACH batch element is read
+ *          flat with L levels (the reference only does this with N == 1; for
+ *          N > 1 every batch element follows the N == 1 rule on its own).
  */
 int dfx_msda_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                                const float *ref, int ref_dim, int Lr,
