@@ -5,11 +5,17 @@ Mirrors the host half of the reference's CUDA op
 argument checks, the same dimension derivation (L from spatial_shapes.size(0), Lq from
 sampling_loc.size(1), P from sampling_loc.size(4)), fresh output tensors.
 """
+import os
+
 import torch
 
 from . import _lib
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+
+# A/B switch for the LDS-tiled kernel of the encoder geometry (csrc/msda_tile.hip); results are
+# identical either way.
+USE_TILE_KERNEL = os.environ.get("DFX_MSDA_TILE", "1") != "0"
 
 # Measurement hook (bench.py): when set to a list, every fused MSDA launch is bracketed by two
 # HIP events recorded on the launch stream and (start, end, algorithmic_bytes, Lq, S) is appended.
@@ -128,12 +134,19 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(value.device))
+    host = getattr(spatial_shapes, "_dfx_host", None)
+    tile = USE_TILE_KERNEL and host is not None and L == 1 and Lr == 1 and Lq == S == host[0][0] * host[0][1]
     with torch.cuda.device(value.device):
-        rc = lib.dfx_msda_fused_forward_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            reference_points.data_ptr(), ref_dim, Lr,
-            base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
-            N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
+        if tile:   # encoder / depth-fusion geometry: queries are the pixels of the (single) value map
+            rc = lib.dfx_msda_fused_tile_forward_f32(
+                value.data_ptr(), reference_points.data_ptr(), ref_dim, base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
+                N, host[0][0], host[0][1], out.data_ptr(), _stream(value.device))
+        else:
+            rc = lib.dfx_msda_fused_forward_f32(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                reference_points.data_ptr(), ref_dim, Lr,
+                base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
+                N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
     if prof is not None:
         e1.record(torch.cuda.current_stream(value.device))
         prof.append((e0, e1, 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D), Lq, S))

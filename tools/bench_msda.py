@@ -64,6 +64,18 @@ def main():
         refp = torch.rand(N, Lq, L, 2, device=dev)
         tf = timeit(lambda: ops.msda_fused_forward(value, shapes, lsi, refp, qproj, L, P), a.iters)
         line += f" | fused {tf*1e6:8.1f} us  {nbytes/tf/1e9:8.1f} GB/s alg"
+        if L == 1 and Lq == S:
+            from models.transformer_layers import make_level_tensors
+            sh2, lsi2 = make_level_tensors(shp, dev)
+            H, W = shp[0]
+            ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
+            grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).view(1, S, 1, 2).expand(N, S, 1, 2).contiguous().to(dev)
+            q2 = qproj.clone()
+            q2[..., : 2 * M * L * P] *= 3.0
+            for flag in (False, True):
+                ops.USE_TILE_KERNEL = flag
+                tt = timeit(lambda: ops.msda_fused_forward(value, sh2, lsi2, grid, q2, L, P), a.iters)
+                line += f" | grid-ref {'tile' if flag else 'wave'} {tt*1e6:8.1f} us {nbytes/tt/1e9:8.1f} GB/s"
         print(line, flush=True)
 
 
