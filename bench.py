@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--conv-autotune", type=int, default=1,
+                    help="let MIOpen time its fp32 solvers per convolution shape during warm-up (cudnn.benchmark)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +112,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the operators have no CPU path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = bool(a.conv_autotune)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)          # RCCL on ROCm
     assert a.frames % world == 0, "the clip must split evenly over the ranks"

@@ -58,15 +58,25 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
     const long S = (long)H * W;
     const float *vb = value + (long)b * S * 256 + h * 32;      // this frame, this head
 
-    // ---- stage the window: 8 threads per position, 32 positions per pass ----
+    // ---- stage the window: 8 threads per position, 32 positions per pass, 6 passes in flight ----
     {
         const int c = tid & 7;
-        for (int ip = tid >> 3; ip < WH * WW; ip += 32) {
-            const int py = wy0 + ip / WW, px = wx0 + ip % WW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (py >= 0 && py < H && px >= 0 && px < W)
-                v = *reinterpret_cast<const float4 *>(vb + ((long)py * W + px) * 256 + c * 4);
-            win[ip * 8 + ((c + (ip >> 1)) & 7)] = v;
+        const int npos = WH * WW;
+        for (int base = tid >> 3; base < npos; base += 32 * 6) {
+            float4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int ip = base + u * 32;
+                const int py = wy0 + ip / WW, px = wx0 + ip % WW;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ip < npos && py >= 0 && py < H && px >= 0 && px < W)
+                    v[u] = *reinterpret_cast<const float4 *>(vb + ((long)py * W + px) * 256 + c * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int ip = base + u * 32;
+                if (ip < npos) win[ip * 8 + ((c + (ip >> 1)) & 7)] = v[u];
+            }
         }
     }
     __syncthreads();

@@ -294,13 +294,13 @@ def test_tile_kernel_matches_oracle(msda, oracle, H, W, N, ref_dim, spread):
         loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
     aw = torch.softmax(qproj[..., 2 * M * P:].reshape(N, S, M, P), -1).view(N, S, M, 1, P)
     expect = oracle.msda_forward(value, shapes.cpu(), lsi.cpu(), loc.contiguous(), aw)
-    assert ops.USE_TILE_KERNEL
-    got = ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, P)
-    assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
-    # and bit-for-bit independent of the route only up to summation order: compare with the wave-per-query kernel
-    ops.USE_TILE_KERNEL = False
+    saved = ops.USE_TILE_KERNEL
     try:
+        ops.USE_TILE_KERNEL = True
+        got = ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, P)
+        ops.USE_TILE_KERNEL = False      # the wave-per-query kernel on the same inputs
         plain = ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, P)
     finally:
-        ops.USE_TILE_KERNEL = True
+        ops.USE_TILE_KERNEL = saved
+    assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
     assert torch.allclose(got, plain, rtol=1e-5, atol=1e-5)

@@ -70,12 +70,13 @@ def main():
             H, W = shp[0]
             ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
             grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).view(1, S, 1, 2).expand(N, S, 1, 2).contiguous().to(dev)
-            q2 = qproj.clone()
-            q2[..., : 2 * M * L * P] *= 3.0
-            for flag in (False, True):
-                ops.USE_TILE_KERNEL = flag
-                tt = timeit(lambda: ops.msda_fused_forward(value, sh2, lsi2, grid, q2, L, P), a.iters)
-                line += f" | grid-ref {'tile' if flag else 'wave'} {tt*1e6:8.1f} us {nbytes/tt/1e9:8.1f} GB/s"
+            for spread in (1.0, 3.0):
+                q2 = qproj.clone()
+                q2[..., : 2 * M * L * P] *= spread
+                for flag in (False, True):
+                    ops.USE_TILE_KERNEL = flag
+                    tt = timeit(lambda: ops.msda_fused_forward(value, sh2, lsi2, grid, q2, L, P), a.iters)
+                    line += f" | sd{spread:.0f}px {'tile' if flag else 'wave'} {tt*1e6:7.1f} us {nbytes/tt/1e9:7.1f} GB/s"
         print(line, flush=True)
 
 
