@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--conv-autotune", type=int, default=1,
+    ap.add_argument("--conv-autotune", type=int, default=0,
                     help="let MIOpen time its fp32 solvers per convolution shape during warm-up (cudnn.benchmark)")
     a = ap.parse_args()
 

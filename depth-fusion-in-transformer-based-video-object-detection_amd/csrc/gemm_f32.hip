@@ -1,0 +1,220 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 256 FLOP/clk/CU) with
+// the fused prologue / epilogues of the deformable-attention path (include/dfx_gemm.h).
+//
+// Structure (CDNA4, wave64):
+//   workgroup = 256 threads = 4 waves laid out WM x WN over a BM x BN output tile; a wave owns
+//   (BM/WM) x (BN/WN) = MT x NT MFMA tiles of 32 x 32, i.e. MT*NT*16 accumulator registers per lane
+//   K is walked in steps of BK = 16 through a double-buffered LDS stage:
+//     As[buf][k][m]  - A (and Linear weights) arrive K-contiguous as 16-byte loads and are
+//                      transposed on the way in (4 scalar LDS stores; row pitch BM+2 keeps the
+//                      stores and the 32-lane fragment reads conflict-free)
+//     Bs[buf][k][n]  - activations of a 1x1 convolution are already [K][N]: 16-byte LDS stores
+//   the next K-step's global loads are issued into registers before the 8 x MT*NT MFMAs of the
+//   current step, and written to the other LDS buffer after them: one barrier per K-step
+//   fragments: lane l reads A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31] with one ds_read_b32
+//   each - 4 LDS reads per 4 MFMAs (256 matrix-pipe cycles) for the 2 x 2 wave tile
+//   epilogue straight from the accumulators (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31):
+//   + bias (per row for convolutions, per column for Linear), + residual, ReLU, zeroing of masked
+//   rows; every store instruction writes 2 rows x 128 contiguous bytes.
+// MFMA-bound: 2*M*N*K flops against 157 TFLOP/s (fp32 matrix peak, MI355X_MICROARCH.md).
+#include "dfx_common.h"
+#include "dfx_gemm.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int BK = 16;
+
+struct Args {
+    const float *A, *A2;
+    long lda, strideA;
+    const float *B;
+    long ldb, strideB;
+    const float *bias;
+    int bias_per_row;
+    const float *R;
+    long ldr, strideR;
+    const unsigned char *mask;
+    long strideMask;
+    float *C;
+    long ldc, strideC;
+    int M, N, K, relu;
+};
+
+template <int BM, int BN, int WM, int WN, bool B_KN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
+{
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+    constexpr int LDA = BM + 2;                       // [k][m] pitch: conflict-free transposed stores
+    constexpr int LDB = B_KN ? BN + 4 : BN + 2;       // [k][n] pitch (16-byte aligned rows when B_KN)
+    constexpr int A_F4 = BM * 4, B_F4 = BN * 4;       // float4 per K-step in the A / B tile
+    constexpr int A_LOADS = (A_F4 + 255) / 256;       // ... per thread (last pass may be partial)
+    constexpr int B_LOADS = (B_F4 + 255) / 256;
+    static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad wave layout");
+    __shared__ float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, c = lane & 31;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long bz = blockIdx.z;
+    const float *A = g.A + bz * g.strideA;
+    const float *A2 = g.A2 ? g.A2 + bz * g.strideA : nullptr;
+    const float *B = g.B + bz * g.strideB;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_LOADS], rb[B_LOADS];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int f = tid + i * 256, row = f >> 2, kq = f & 3;
+            const int m = m0 + row, k = k0 + kq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < A_F4 && m < g.M && k < g.K) {
+                v = *reinterpret_cast<const float4 *>(A + (long)m * g.lda + k);
+                if (A2) {
+                    const float4 w = *reinterpret_cast<const float4 *>(A2 + (long)m * g.lda + k);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int f = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_KN) {
+                const int kr = f / (BN / 4), nq = f % (BN / 4);
+                const int k = k0 + kr, n = n0 + nq * 4;
+                if (f < B_F4 && k < g.K && n < g.N) v = *reinterpret_cast<const float4 *>(B + (long)k * g.ldb + n);
+            } else {
+                const int row = f >> 2, kq = f & 3;
+                const int n = n0 + row, k = k0 + kq * 4;
+                if (f < B_F4 && n < g.N && k < g.K) v = *reinterpret_cast<const float4 *>(B + (long)n * g.ldb + k);
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int f = tid + i * 256, row = f >> 2, kq = f & 3;
+            if (f >= A_F4) continue;
+            As[buf][kq * 4 + 0][row] = ra[i].x;
+            As[buf][kq * 4 + 1][row] = ra[i].y;
+            As[buf][kq * 4 + 2][row] = ra[i].z;
+            As[buf][kq * 4 + 3][row] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int f = tid + i * 256;
+            if (f >= B_F4) continue;
+            if (B_KN) {
+                const int kr = f / (BN / 4), nq = f % (BN / 4);
+                *reinterpret_cast<float4 *>(&Bs[buf][kr][nq * 4]) = rb[i];
+            } else {
+                const int row = f >> 2, kq = f & 3;
+                Bs[buf][kq * 4 + 0][row] = rb[i].x;
+                Bs[buf][kq * 4 + 1][row] = rb[i].y;
+                Bs[buf][kq * 4 + 2][row] = rb[i].z;
+                Bs[buf][kq * 4 + 3][row] = rb[i].w;
+            }
+        }
+    };
+
+    const int steps = (g.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int t = 0; t < steps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < steps) load_tiles((t + 1) * BK);          // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = As[buf][kk * 2 + half][wm * TM + i * 32 + c];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = Bs[buf][kk * 2 + half][wn * TN + j * 32 + c];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < steps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    float *C = g.C + bz * g.strideC;
+    const float *R = g.R ? g.R + bz * g.strideR : nullptr;
+    const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * TN + j * 32 + c;
+            const float bn = (g.bias && !g.bias_per_row && n < g.N) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r] + bn;
+                    if (g.bias && g.bias_per_row) v += g.bias[m];
+                    if (R) v += R[(long)m * g.ldr + n];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (mask && mask[m]) v = 0.f;
+                    C[(long)m * g.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
+{
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch), block(256);
+    if (b_is_kn)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, g);
+    return dfx::check_launch("gemm_f32_kernel");
+}
+
+}  // namespace
+
+extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long strideA, const float *B, long ldb,
+                            long strideB, int b_is_kn, const float *bias, int bias_per_row, const float *R,
+                            long ldr, long strideR, const unsigned char *row_mask, long strideMask, float *C,
+                            long ldc, long strideC, int M, int N, int K, int batch, int relu, void *stream)
+{
+    if (M < 0 || N < 0 || K <= 0 || batch < 0) return dfx::fail(DFX_EINVAL, "gemm: bad dimension");
+    if ((long)M * N * batch == 0) return DFX_OK;
+    if (!A || !B || !C) return dfx::fail(DFX_EINVAL, "gemm: null pointer");
+    if ((K & 3) || (lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3) || !dfx::aligned16(A) || !dfx::aligned16(B) ||
+        (A2 && !dfx::aligned16(A2)) || (b_is_kn && (N & 3)))
+        return dfx::fail(DFX_EINVAL, "gemm: K (and N for [K,N] operands) must be multiples of 4, rows 16-byte aligned");
+    if (batch > 65535) return dfx::fail(DFX_ERANGE, "gemm: batch too large");
+    Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
+           M, N, K, relu};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // tile choice: full 128 x 128 tiles when they fill the chip, narrower tiles for small M / N
+    const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (M <= 64) return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
+    if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
+    if (N <= 64) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+    if (N <= 96) return launch<128, 96, 4, 1>(g, batch, b_is_kn, st);
+    if (big < 512) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+    return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+}

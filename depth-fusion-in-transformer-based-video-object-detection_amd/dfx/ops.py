@@ -202,3 +202,65 @@ def bias_act_(x, bias, residual=None, relu=True):
                                        x.data_ptr(), N, C, hw, int(bool(relu)), _stream(x.device))
     _lib.check(rc, "bias_act_")
     return x
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None):
+    """y = act((x (+ add)) @ weight.T + bias (+ residual)), rows where row_mask is True set to 0.
+    The hand-written fp32 MFMA GEMM (include/dfx_gemm.h) standing in for nn.Linear with its
+    neighbours fused: the ``src + pos`` query add, the bias, ReLU, the residual add and
+    value_proj's masked_fill.  x [..., K] contiguous, weight [N, K] -> [..., N]."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    named = [("x", x2), ("weight", weight)]
+    for nm, t in (("bias", bias), ("residual", residual), ("add", add), ("row_mask", row_mask)):
+        if t is not None:
+            named.append((nm, t))
+    _check_inputs(named)
+    _require(x2.dtype == torch.float32 and weight.dtype == torch.float32, "linear is implemented for float32")
+    _require(weight.shape[1] == K and K % 4 == 0, "weight must be [N, K] with K a multiple of 4")
+    if add is not None:
+        _require(add.shape == x.shape, "add must match x")
+    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        _require(residual.shape == out.shape, "residual must match the output")
+    if row_mask is not None:
+        _require(row_mask.numel() == M, "row_mask must have one entry per row")
+        row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
+    with torch.cuda.device(x.device):
+        rc = lib.dfx_gemm_f32(x2.data_ptr(), _ptr(add), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), 0,
+                              _ptr(residual), N, 0, _ptr(row_mask), 0, out.data_ptr(), N, 0, M, N, K, 1,
+                              int(bool(relu)), _stream(x.device))
+    _lib.check(rc, "linear")
+    return out
+
+
+def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
+    """1x1 convolution on NCHW as a batched GEMM W[Co,Ci] x X_n[Ci,HW] with the folded-BN bias,
+    the residual add and ReLU fused into the epilogue.  x [N,Ci,H,W], weight [Co,Ci(,1,1)]."""
+    lib = _lib.load()
+    if stride != 1:
+        x = x[:, :, ::stride, ::stride].contiguous()
+    Nb, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    w2 = weight.reshape(Co, -1)
+    named = [("x", x), ("weight", w2)] + [(n, t) for n, t in (("bias", bias), ("residual", residual)) if t is not None]
+    _check_inputs(named)
+    _require(x.dtype == torch.float32 and w2.shape[1] == Ci, "conv1x1: fp32, weight [Co,Ci]")
+    HW = H * W
+    _require(Ci % 4 == 0 and HW % 4 == 0, "conv1x1 needs Ci and H*W to be multiples of 4")
+    out = torch.empty((Nb, Co, H, W), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        _require(residual.shape == out.shape, "residual must match the output")
+    with torch.cuda.device(x.device):
+        rc = lib.dfx_gemm_f32(w2.data_ptr(), 0, Ci, 0, x.data_ptr(), HW, Ci * HW, 1, _ptr(bias), 1,
+                              _ptr(residual), HW, Co * HW, 0, 0, out.data_ptr(), HW, Co * HW, Co, HW, Ci, Nb,
+                              int(bool(relu)), _stream(x.device))
+    _lib.check(rc, "conv1x1")
+    return out

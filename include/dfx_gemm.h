@@ -1,0 +1,45 @@
+/*
+ * dfx_gemm.h -- C ABI of the hand-written fp32 MFMA GEMM (gfx950, v_mfma_f32_32x32x2_f32) with the
+ * fused prologue / epilogues the deformable-attention path needs.
+ *
+ * It stands where the reference calls PyTorch library GEMMs on this path:
+ *   nn.Linear value_proj / sampling_offsets / attention_weights / output_proj
+ *                                   /root/reference/models/ops/modules/ms_deform_attn.py:94-100,116
+ *   FFN linear1 (+ReLU) / linear2   /root/reference/models/deformable_transformer_single.py:544-548
+ *   Late Fusion adapt / FFN Linears /root/reference/models/deformable_transformer_single.py:379-402
+ *   1x1 convolutions of ResNet-50 (+ folded FrozenBatchNorm2d, ReLU, residual add)
+ *                                   /root/reference/models/backbone_scratch.py:102-141 (torchvision Bottleneck)
+ *   input_proj 1x1 convolution      /root/reference/models/deformable_detr_single.py:101-125
+ *
+ *   C[b] = act( (A[b] (+ A2[b])) x op(B[b]) + bias (+ R[b]) ), rows with row_mask != 0 forced to 0
+ *
+ *   A   [M,K] row-major, leading dimension lda; batch stride strideA (0 = shared by all batches)
+ *   A2  optional, same layout as A, added element-wise while A is staged (query = src + pos)
+ *   B   b_is_kn = 1: [K,N] row-major (ldb >= N)  -- activations of a 1x1 convolution, NCHW
+ *       b_is_kn = 0: [N,K] row-major (ldb >= K)  -- an nn.Linear weight
+ *   bias optional; bias_per_row = 1: bias[m] (convolution), 0: bias[n] (Linear)
+ *   R   optional residual, layout of C (ldr, strideR)
+ *   row_mask optional uint8[M] per batch (strideMask): value_proj's masked_fill of padded tokens
+ *   C   [M,N] row-major, ldc
+ * fp32 in, fp32 accumulate (exact fp32 MFMA), fp32 out.  K must be a multiple of 4; A, B rows
+ * 16-byte aligned.  Same conventions as dfx_msda.h (device pointers, enqueue-only, 0 / <0).
+ */
+#ifndef DFX_GEMM_H
+#define DFX_GEMM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int dfx_gemm_f32(const float *A, const float *A2, long lda, long strideA,
+                 const float *B, long ldb, long strideB, int b_is_kn,
+                 const float *bias, int bias_per_row,
+                 const float *R, long ldr, long strideR,
+                 const unsigned char *row_mask, long strideMask,
+                 float *C, long ldc, long strideC,
+                 int M, int N, int K, int batch, int relu, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFX_GEMM_H */
