@@ -1,0 +1,58 @@
+"""GPU: the hand-written fp32 MFMA GEMM (csrc/gemm_f32.hip) against a float64 reference.
+fp32 MFMA is an exact-fp32 k-ordered fma chain, so the error bound is the usual sum-of-products
+one: we assert 4e-6 * sqrt(K) * scale."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_linear(x, w, b, relu, res, add, mask):
+    y = (x.double() + (0 if add is None else add.double())) @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if res is not None:
+        y = y + res.double()
+    if relu:
+        y = y.relu()
+    if mask is not None:
+        y = y.masked_fill(mask[..., None], 0.0)
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(4200, 256, 256), (33600, 96, 256), (300, 256, 256), (1000, 1024, 256),
+                                   (777, 256, 1024), (64, 128, 2048), (130, 3, 256), (5, 4, 8), (2500, 64, 128),
+                                   (129, 300, 260)])
+@pytest.mark.parametrize("variant", ["plain", "bias_relu", "all"])
+def test_linear_matches_fp64(M, N, K, variant):
+    from dfx import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if variant != "plain" else None
+    res = torch.randn(M, N, generator=g).cuda() if variant == "all" else None
+    add = torch.randn(M, K, generator=g).cuda() if variant == "all" else None
+    mask = (torch.rand(M, generator=g) > 0.8).cuda() if variant == "all" else None
+    got = ops.linear(x, w, b, relu=variant != "plain", residual=res, add=add, row_mask=mask)
+    want = _ref_linear(x, w, b, variant != "plain", res, add, mask)
+    tol = 4e-6 * K ** 0.5 * (2.0 if add is not None else 1.0)
+    assert got.shape == (M, N)
+    assert (got.double() - want).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("Nb,Ci,Co,H,W", [(2, 64, 256, 20, 34), (3, 256, 64, 10, 18), (1, 1024, 512, 8, 12),
+                                          (2, 2048, 256, 5, 8), (2, 128, 256, 50, 84)])
+def test_conv1x1_matches_torch(Nb, Ci, Co, H, W):
+    from dfx import ops
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(Nb, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    r = torch.randn(Nb, Co, H, W, generator=g).cuda()
+    want = (torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double()).relu()
+    got = ops.conv1x1(x, w, b, residual=r, relu=True)
+    assert (got.double() - want).abs().max().item() < 4e-6 * Ci ** 0.5
+    if (((H + 1) // 2) * ((W + 1) // 2)) % 4 == 0:
+        want2 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=2)
+        got2 = ops.conv1x1(x, w, stride=2)
+        assert (got2.double() - want2).abs().max().item() < 4e-6 * Ci ** 0.5
