@@ -71,37 +71,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_LOADS], rb[B_LOADS];
+    float4 ra[A_LOADS], ra2[A_LOADS], rb[B_LOADS];
+    bool oka[A_LOADS], okb[B_LOADS];     // zeroing of out-of-range lanes happens at LDS-store time, so the
+                                         // loads stay in flight across the MFMAs of the current K-step
 
+    // loads are unconditional: indices are clamped into the operand and out-of-range lanes are
+    // zeroed by a select afterwards, so the compiler can keep every load of a K-step in flight
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int f = tid + i * 256, row = f >> 2, kq = f & 3;
             const int m = m0 + row, k = k0 + kq * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < A_F4 && m < g.M && k < g.K) {
-                v = *reinterpret_cast<const float4 *>(A + (long)m * g.lda + k);
-                if (A2) {
-                    const float4 w = *reinterpret_cast<const float4 *>(A2 + (long)m * g.lda + k);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                }
-            }
-            ra[i] = v;
+            oka[i] = m < g.M && k < g.K;
+            const long o = (long)min(m, g.M - 1) * g.lda + min(k, g.K - 4);
+            ra[i] = *reinterpret_cast<const float4 *>(A + o);
+            if (A2) ra2[i] = *reinterpret_cast<const float4 *>(A2 + o);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int f = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (B_KN) {
                 const int kr = f / (BN / 4), nq = f % (BN / 4);
                 const int k = k0 + kr, n = n0 + nq * 4;
-                if (f < B_F4 && k < g.K && n < g.N) v = *reinterpret_cast<const float4 *>(B + (long)k * g.ldb + n);
+                okb[i] = k < g.K && n < g.N;
+                rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
             } else {
                 const int row = f >> 2, kq = f & 3;
                 const int n = n0 + row, k = k0 + kq * 4;
-                if (f < B_F4 && n < g.N && k < g.K) v = *reinterpret_cast<const float4 *>(B + (long)n * g.ldb + k);
+                okb[i] = n < g.N && k < g.K;
+                rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(n, g.N - 1) * g.ldb + min(k, g.K - 4));
             }
-            rb[i] = v;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -109,24 +109,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
         for (int i = 0; i < A_LOADS; ++i) {
             const int f = tid + i * 256, row = f >> 2, kq = f & 3;
             if (f >= A_F4) continue;
-            As[buf][kq * 4 + 0][row] = ra[i].x;
-            As[buf][kq * 4 + 1][row] = ra[i].y;
-            As[buf][kq * 4 + 2][row] = ra[i].z;
-            As[buf][kq * 4 + 3][row] = ra[i].w;
+            float4 v = ra[i];
+            if (A2) { v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w; }
+            if (!oka[i]) v = zero4;
+            As[buf][kq * 4 + 0][row] = v.x;
+            As[buf][kq * 4 + 1][row] = v.y;
+            As[buf][kq * 4 + 2][row] = v.z;
+            As[buf][kq * 4 + 3][row] = v.w;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int f = tid + i * 256;
             if (f >= B_F4) continue;
+            const float4 v = okb[i] ? rb[i] : zero4;
             if (B_KN) {
                 const int kr = f / (BN / 4), nq = f % (BN / 4);
-                *reinterpret_cast<float4 *>(&Bs[buf][kr][nq * 4]) = rb[i];
+                *reinterpret_cast<float4 *>(&Bs[buf][kr][nq * 4]) = v;
             } else {
                 const int row = f >> 2, kq = f & 3;
-                Bs[buf][kq * 4 + 0][row] = rb[i].x;
-                Bs[buf][kq * 4 + 1][row] = rb[i].y;
-                Bs[buf][kq * 4 + 2][row] = rb[i].z;
-                Bs[buf][kq * 4 + 3][row] = rb[i].w;
+                Bs[buf][kq * 4 + 0][row] = v.x;
+                Bs[buf][kq * 4 + 1][row] = v.y;
+                Bs[buf][kq * 4 + 2][row] = v.z;
+                Bs[buf][kq * 4 + 3][row] = v.w;
             }
         }
     };
@@ -138,18 +142,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     for (int t = 0; t < steps; ++t) {
         const int buf = t & 1;
         if (t + 1 < steps) load_tiles((t + 1) * BK);          // in flight during the MFMAs below
+        // fragments of k-pair kk+1 are read while the MFMAs of k-pair kk run
+        float a[2][MT], b[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[0][i] = As[buf][half][wm * TM + i * 32 + c];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[0][j] = Bs[buf][half][wn * TN + j * 32 + c];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[MT], b[NT];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = As[buf][kk * 2 + half][wm * TM + i * 32 + c];
+                for (int i = 0; i < MT; ++i) a[nxt][i] = As[buf][kk * 2 + 2 + half][wm * TM + i * 32 + c];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = Bs[buf][kk * 2 + half][wn * TN + j * 32 + c];
+                for (int j = 0; j < NT; ++j) b[nxt][j] = Bs[buf][kk * 2 + 2 + half][wn * TN + j * 32 + c];
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < steps) store_tiles(buf ^ 1);
         __syncthreads();
@@ -159,23 +171,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     float *C = g.C + bz * g.strideC;
     const float *R = g.R ? g.R + bz * g.strideR : nullptr;
     const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
+    const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
+    int ncol[NT];
+    float bcolv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        ncol[j] = n0 + wn * TN + j * 32 + c;
+        bcolv[j] = bcol ? g.bias[min(ncol[j], g.N - 1)] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn * TN + j * 32 + c;
-            const float bn = (g.bias && !g.bias_per_row && n < g.N) ? g.bias[n] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int mc = min(m, g.M - 1);                         // clamped: branch-free loads
+            const float rb = brow ? g.bias[mc] : 0.f;
+            const bool rz = mask ? mask[mc] != 0 : false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < g.M && n < g.N) {
-                    float v = acc[i][j][r] + bn;
-                    if (g.bias && g.bias_per_row) v += g.bias[m];
-                    if (R) v += R[(long)m * g.ldr + n];
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    if (mask && mask[m]) v = 0.f;
-                    C[(long)m * g.ldc + n] = v;
-                }
+            for (int j = 0; j < NT; ++j) {
+                float v = acc[i][j][r] + bcolv[j] + rb;
+                if (R) v += R[(long)mc * g.ldr + min(ncol[j], g.N - 1)];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (rz) v = 0.f;
+                if (m < g.M && ncol[j] < g.N) C[(long)m * g.ldc + ncol[j]] = v;
             }
         }
     }
@@ -209,12 +227,22 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
            M, N, K, relu};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // tile choice: full 128 x 128 tiles when they fill the chip, narrower tiles for small M / N
-    const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    // tile choice.  Small M / N pick the matching narrow tile.  Otherwise weigh the operand reuse of
+    // the 128 x 128 tile against how evenly the grid spreads over the 256 CUs (all workgroups are
+    // co-resident at these sizes, so a CU holding ceil(blocks/256) workgroups sets the time).
     if (M <= 64) return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
     if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
     if (N <= 64) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
     if (N <= 96) return launch<128, 96, 4, 1>(g, batch, b_is_kn, st);
-    if (big < 512) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
-    return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    auto balance = [&](int bm, int bn) {
+        const double blocks = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+        const double per_cu = blocks / 256.0;
+        const double fill = per_cu / (double)(long)(per_cu + 0.999999);      // 1.0 = perfectly even
+        const double edge = ((double)M * N) / ((double)((M + bm - 1) / bm * bm) * ((N + bn - 1) / bn * bn));
+        return fill * edge;
+    };
+    const double s128 = balance(128, 128), s64n = 0.90 * balance(128, 64), s64m = 0.90 * balance(64, 128);
+    if (s128 >= s64n && s128 >= s64m) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    if (s64n >= s64m) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+    return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }

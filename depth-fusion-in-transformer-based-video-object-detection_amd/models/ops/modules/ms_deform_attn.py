@@ -79,10 +79,11 @@ class MSDeformAttn(nn.Module):
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
-        """query [N,Lq,C]; reference_points [N,Lq,L,2] (or 4: cx,cy,w,h) in [0,1];
+        """query [N,Lq,C] (or a (tensor, positional_embedding) pair whose sum is the query: the add is
+        then fused into the projection GEMM); reference_points [N,Lq,L,2] (or 4: cx,cy,w,h) in [0,1];
         input_flatten [N,sum(H_l*W_l),C]; input_spatial_shapes i64 [L,2]; input_level_start_index
         i64 [L]; input_padding_mask [N,S] True = padding.  -> [N,Lq,C]   (ref :78-117)"""
-        N, Lq, _ = query.shape
+        N, Lq, _ = (query[0] if isinstance(query, tuple) else query).shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
         D = self.d_model // M
@@ -94,19 +95,36 @@ class MSDeformAttn(nn.Module):
         if ref_dim not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref_dim} instead.")
 
+        no_grad = not torch.is_grad_enabled() or not (query.requires_grad or input_flatten.requires_grad)
+        fused = no_grad and input_flatten.is_cuda and input_flatten.dtype == torch.float32 \
+            and _ops.fused_supported(input_flatten, M, D, L, P, reference_points.shape[2])
+        if fused:
+            # value_proj (+ masked_fill of padded tokens), [offsets | logits] in one GEMM (+ the
+            # caller's ``src + pos`` add when handed over as a (src, pos) pair), fused sampling
+            big = N * S >= 2048       # hand-written MFMA GEMM pays off on the token-sized calls
+            q, q_add = query if isinstance(query, tuple) else (query, None)
+            w, b = self._qproj_params()
+            if big:
+                value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
+                                    row_mask=input_padding_mask)
+            else:
+                value = self.value_proj(input_flatten)
+                if input_padding_mask is not None:
+                    value = value.masked_fill(input_padding_mask[..., None], float(0))
+            if N * Lq >= 2048:
+                qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous())
+            else:
+                qproj = F.linear(q if q_add is None else q + q_add, w, b)
+            sampled = _ops.msda_fused_forward(value.view(N, S, M, D), input_spatial_shapes, input_level_start_index,
+                                              reference_points, qproj, L, P)
+            return self.output_proj(sampled)
+        if isinstance(query, tuple):
+            query = query[0] + query[1]
+
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, S, M, D)
-
-        fused = (not torch.is_grad_enabled() or not (query.requires_grad or value.requires_grad)) \
-            and _ops.fused_supported(value, M, D, L, P, reference_points.shape[2]) and value.is_contiguous()
-        if fused:
-            w, b = self._qproj_params()
-            qproj = F.linear(query, w, b)
-            sampled = _ops.msda_fused_forward(value, input_spatial_shapes, input_level_start_index,
-                                              reference_points, qproj, L, P)
-            return self.output_proj(sampled)
 
         offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
         weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)

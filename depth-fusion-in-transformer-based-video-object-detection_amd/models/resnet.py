@@ -56,16 +56,30 @@ class Bottleneck(nn.Module):
         return self._folded[1]
 
     def forward_fused(self, x):
-        """Inference on the GPU: frozen BN folded into the convolutions, bias + (residual) + ReLU in
-        one in-place pass (dfx.ops.bias_act_).  No CPU route."""
+        """Inference on the GPU: frozen BN folded into the convolutions.  The 1x1 convolutions whose
+        epilogue traffic dominates (conv3 with its residual add + ReLU everywhere; conv1 and the
+        shortcut on the large early maps) run on the hand-written MFMA GEMM with bias / residual /
+        ReLU fused (dfx.ops.conv1x1); the 3x3 convolutions stay on the library with one fused
+        in-place epilogue pass (dfx.ops.bias_act_).  Choice per layer from tools/bench_gemm.py.
+        No CPU route."""
         (w1, b1), (w2, b2), (w3, b3), down = self._folded_params()
         c2 = self.conv2
-        out = _ops.bias_act_(F.conv2d(x, w1), b1, relu=True)
+        big = x.shape[2] * x.shape[3] >= 40000 and (x.shape[2] * x.shape[3]) % 4 == 0
+        gemm_ok = (x.shape[2] * x.shape[3]) % 4 == 0
+        if big:
+            out = _ops.conv1x1(x, w1, b1, relu=True)
+        else:
+            out = _ops.bias_act_(F.conv2d(x, w1), b1, relu=True)
         out = _ops.bias_act_(F.conv2d(out, w2, None, c2.stride, c2.padding, c2.dilation), b2, relu=True)
-        out = F.conv2d(out, w3)
         if down is not None:
-            x = _ops.bias_act_(F.conv2d(x, down[0], None, self.downsample[0].stride), down[1], relu=False)
-        return _ops.bias_act_(out, b3, residual=x, relu=True)
+            stride = self.downsample[0].stride[0]
+            if big and stride == 1:
+                x = _ops.conv1x1(x, down[0], down[1], relu=False)
+            else:
+                x = _ops.bias_act_(F.conv2d(x, down[0], None, stride), down[1], relu=False)
+        if gemm_ok and (out.shape[2] * out.shape[3]) % 4 == 0:
+            return _ops.conv1x1(out, w3, b3, residual=x, relu=True)
+        return _ops.bias_act_(F.conv2d(out, w3), b3, residual=x, relu=True)
 
     def forward(self, x):
         out = self.relu(self.bn1(self.conv1(x)))

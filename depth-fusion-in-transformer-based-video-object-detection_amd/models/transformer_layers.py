@@ -102,9 +102,19 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 rgbd_src=None):
-        query = rgbd_src if rgbd_src is not None else _add_pos(src, pos)
+        fused = src.is_cuda and not torch.is_grad_enabled() and src.dtype == torch.float32
+        if rgbd_src is not None:
+            query = rgbd_src
+        elif fused and pos is not None:
+            query = (src, pos)                     # the add rides along into the projection GEMM
+        else:
+            query = _add_pos(src, pos)
         y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(y))
+        if fused and self.activation is F.relu and src.shape[0] * src.shape[1] >= 2048:
+            from dfx import ops as _ops            # linear1 + bias + ReLU in one MFMA GEMM
+            h = _ops.linear(src.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
+            return self.norm2(src + self.linear2(h))
         return self.forward_ffn(src)
 
 
