@@ -107,6 +107,11 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // geometry of the 4 points first: weights, clamped corner coordinates, and whether every
+    // corner of this lane lies inside the staged window
+    float cw[4][4];
+    int cyx[4][4];          // window-relative (iy << 16 | ix) when inside, absolute (cy << 16 | cx) otherwise
+    bool inside = true;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         float lx, ly;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
             ly = ry + oy[p] / 4.f * rh * 0.5f;
         }
         const float a = e[p] / sum;
-        // geometry: ms_deform_im2col_cuda.cuh:281-291 (skip rule) and :33-84 (corners)
+        // ms_deform_im2col_cuda.cuh:281-291 (skip rule) and :33-84 (corners)
         const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
         const bool inr = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
         const float hf = floorf(fminf(fmaxf(h_im, -1.f), (float)H));
@@ -126,25 +131,52 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
         const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
         const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
         const bool top = inr && h0 >= 0, bot = inr && h1 <= H - 1, lef = w0 >= 0, rig = w1 <= W - 1;
-        const float cw[4] = {(top && lef) ? hh * hw * a : 0.f, (top && rig) ? hh * lw * a : 0.f,
-                             (bot && lef) ? lh * hw * a : 0.f, (bot && rig) ? lh * lw * a : 0.f};
+        cw[p][0] = (top && lef) ? hh * hw * a : 0.f;
+        cw[p][1] = (top && rig) ? hh * lw * a : 0.f;
+        cw[p][2] = (bot && lef) ? lh * hw * a : 0.f;
+        cw[p][3] = (bot && rig) ? lh * lw * a : 0.f;
         const int y0 = max(min(h0, H - 1), 0), y1 = max(min(h1, H - 1), 0);
         const int x0 = max(min(w0, W - 1), 0), x1 = max(min(w1, W - 1), 0);
-        const int cy[4] = {y0, y0, y1, y1}, cx[4] = {x0, x1, x0, x1};
+        const bool in_p = (y0 >= wy0) && (y1 < wy0 + WH) && (x0 >= wx0) && (x1 < wx0 + WW);
+        inside = inside && in_p;
+        cyx[p][0] = (y0 << 16) | x0; cyx[p][1] = (y0 << 16) | x1;
+        cyx[p][2] = (y1 << 16) | x0; cyx[p][3] = (y1 << 16) | x1;
+    }
+
+    if (__all(inside)) {
+        // fast path, whole wave: every corner is staged - unconditional LDS reads, no branches
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int iy = cy[c] - wy0, ix = cx[c] - wx0;
-            const float wgt = cw[c];
-            if (iy >= 0 && iy < WH && ix >= 0 && ix < WW) {          // staged: LDS
-                const int ip = iy * WW + ix;
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ip = ((cyx[p][c] >> 16) - wy0) * WW + ((cyx[p][c] & 0xffff) - wx0);
                 const float4 *row = win + ip * 8;
                 const int sw = ip >> 1;
+                float4 v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) fma4(acc[k], wgt, row[(k + sw) & 7]);
-            } else if (wgt != 0.f) {                                 // outside the window: global
-                const float4 *row = reinterpret_cast<const float4 *>(vb + ((long)cy[c] * W + cx[c]) * 256);
+                for (int k = 0; k < 8; ++k) v[k] = row[(k + sw) & 7];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) fma4(acc[k], wgt, row[k]);
+                for (int k = 0; k < 8; ++k) fma4(acc[k], cw[p][c], v[k]);
+            }
+        }
+    } else {
+        // some lane samples outside its tile's window (large learned offsets): per-corner choice
+        for (int p = 0; p < 4; ++p) {
+            for (int c = 0; c < 4; ++c) {
+                const int gy = cyx[p][c] >> 16, gx = cyx[p][c] & 0xffff;
+                const int iy = gy - wy0, ix = gx - wx0;
+                const float wgt = cw[p][c];
+                if (iy >= 0 && iy < WH && ix >= 0 && ix < WW) {
+                    const int ip = iy * WW + ix;
+                    const float4 *row = win + ip * 8;
+                    const int sw = ip >> 1;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) fma4(acc[k], wgt, row[(k + sw) & 7]);
+                } else if (wgt != 0.f) {
+                    const float4 *row = reinterpret_cast<const float4 *>(vb + ((long)gy * W + gx) * 256);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) fma4(acc[k], wgt, row[k]);
+                }
             }
         }
     }
