@@ -1,0 +1,84 @@
+"""CPU: the caller-side steps around the path."""
+import torch
+
+from models import inference_io as io
+
+
+def test_reference_frame_sampling_rule():
+    ids = list(range(100, 120))
+    assert io.sample_reference_ids(110, ids, 4) == [106, 107, 108, 109]            # window minus the key frame
+    assert io.sample_reference_ids(100, ids, 4) == [101, 102, 103, 104]            # clipped at the start
+    assert io.sample_reference_ids(119, ids, 4) == [115, 116, 117, 118]
+    assert io.sample_reference_ids(110, ids, 4, filter_key_img=False) == [106, 107, 108, 109]
+    assert io.sample_reference_ids(5, [4, 5], 3) == [4, 4, 4]                       # short video: repeat
+
+
+def test_clip_assembly_round_trips_through_the_collate():
+    from util.misc_multi import nested_tensor_from_tensor_list
+    g = torch.Generator().manual_seed(0)
+    rgb = [torch.randn(3, 8, 10, generator=g) for _ in range(3)]
+    dep = [torch.randn(1, 8, 10, generator=g) for _ in range(3)]
+    clip = io.assemble_clip(rgb, dep)
+    assert clip.shape == (12, 8, 10)
+    nt = nested_tensor_from_tensor_list([clip], split=True, channel_size=4)
+    assert nt.tensors.shape == (3, 4, 8, 10)
+    for t in range(3):
+        assert torch.equal(nt.tensors[t, :3], rgb[t]) and torch.equal(nt.tensors[t, 3:], dep[t])
+    assert io.assemble_clip(rgb).shape == (9, 8, 10)
+
+
+def test_post_filter_rescale_and_label_lines():
+    logits = torch.tensor([[[0.0, 3.0, 0.0], [2.0, 0.0, 0.0], [0.0, 0.2, 0.0]]])
+    boxes = torch.tensor([[[0.5, 0.5, 0.2, 0.4], [0.1, 0.1, 0.1, 0.1], [0.3, 0.6, 0.2, 0.2]]])
+    probs, kept, idx = io.filter_detections({"pred_logits": logits, "pred_boxes": boxes}, keep_prob=0.5)
+    assert idx.tolist() == [0] and torch.allclose(probs, logits.softmax(-1)[0, :1, 1])
+    px = io.rescale_bboxes(kept, (200, 100))
+    assert torch.allclose(px, torch.tensor([[80.0, 30.0, 120.0, 70.0]]))
+    line = io.yolo_lines(kept, probs)[0].split()
+    assert line[0] == "Hand" and len(line) == 6 and abs(float(line[1]) - 0.5) < 1e-7
+
+
+def test_checkpoint_merge_and_load(tmp_path):
+    """{'model': state_dict} wire format; temporal modules come from the TransVOD++ checkpoint, the
+    spatial fine-tune overlays everything it holds; keys are the reference's."""
+    torch.manual_seed(0)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(2, 2)
+            self.temporal_query_layer1 = torch.nn.Linear(2, 2)
+            self.dynamic_layer_for_current_query1 = torch.nn.Linear(2, 2)
+            self.temp_bbox_embed = torch.nn.Linear(2, 2)
+            self.class_embed = torch.nn.Linear(2, 2)
+
+    base, temporal, spatial, target = Tiny(), Tiny(), Tiny(), Tiny()
+    p = {n: str(tmp_path / f"{n}.pth") for n in ("base", "temporal", "spatial")}
+    torch.save({"model": base.state_dict(), "epoch": 3}, p["base"])
+    torch.save({"model": {**temporal.state_dict(), "x.total_ops": torch.zeros(1)}}, p["temporal"])
+    torch.save({"model": {k: v for k, v in spatial.state_dict().items() if k.startswith("backbone")}}, p["spatial"])
+    missing, unexpected = io.load_checkpoint(target, p["base"], p["spatial"], p["temporal"], "vid_multi_plusplus")
+    assert missing == [] and unexpected == []
+    sd = target.state_dict()
+    assert torch.equal(sd["backbone.weight"], spatial.state_dict()["backbone.weight"])
+    assert torch.equal(sd["temporal_query_layer1.weight"], temporal.state_dict()["temporal_query_layer1.weight"])
+    assert torch.equal(sd["dynamic_layer_for_current_query1.bias"], temporal.state_dict()["dynamic_layer_for_current_query1.bias"])
+    assert torch.equal(sd["temp_bbox_embed.weight"], temporal.state_dict()["temp_bbox_embed.weight"])
+    assert torch.equal(sd["class_embed.weight"], base.state_dict()["class_embed.weight"])
+    # TransVOD (vid_multi) does not move the dynamic_layer weights
+    io.load_checkpoint(target, p["base"], None, p["temporal"], "vid_multi")
+    assert torch.equal(target.state_dict()["dynamic_layer_for_current_query1.bias"],
+                       base.state_dict()["dynamic_layer_for_current_query1.bias"])
+
+
+def test_real_model_state_dict_round_trip(tmp_path):
+    from models import build_model
+    from models.config import single_args
+    model, _, _ = build_model(single_args("LateFusion", device="cpu"))
+    path = str(tmp_path / "ck.pth")
+    torch.save({"model": model.state_dict()}, path)
+    other, _, _ = build_model(single_args("LateFusion", device="cpu"))
+    missing, unexpected = io.load_checkpoint(other, path)
+    assert missing == [] and unexpected == []
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
