@@ -19,11 +19,11 @@
 // MFMA-bound: 2*M*N*K flops against 157 TFLOP/s (fp32 matrix peak, MI355X_MICROARCH.md).
 #include "dfx_common.h"
 #include "dfx_gemm.h"
+#include <stdlib.h>
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int BK = 16;
 
 struct Args {
     const float *A, *A2;
@@ -41,13 +41,14 @@ struct Args {
     int M, N, K, relu;
 };
 
-template <int BM, int BN, int WM, int WN, bool B_KN>
+template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int LDA = BM + 2;                       // [k][m] pitch: conflict-free transposed stores
     constexpr int LDB = B_KN ? BN + 4 : BN + 2;       // [k][n] pitch (16-byte aligned rows when B_KN)
-    constexpr int A_F4 = BM * 4, B_F4 = BN * 4;       // float4 per K-step in the A / B tile
+    constexpr int KQ = BK / 4;                        // float4 per row per K-step
+    constexpr int A_F4 = BM * KQ, B_F4 = BN * KQ;     // (= BK * BN / 4 for the [K][N] operand as well)     // float4 per K-step in the A / B tile
     constexpr int A_LOADS = (A_F4 + 255) / 256;       // ... per thread (last pass may be partial)
     constexpr int B_LOADS = (B_F4 + 255) / 256;
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad wave layout");
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * 256, row = f >> 2, kq = f & 3;
+            const int f = tid + i * 256, row = f / KQ, kq = f % KQ;
             const int m = m0 + row, k = k0 + kq * 4;
             oka[i] = m < g.M && k < g.K;
             const long o = (long)min(m, g.M - 1) * g.lda + min(k, g.K - 4);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 okb[i] = k < g.K && n < g.N;
                 rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
             } else {
-                const int row = f >> 2, kq = f & 3;
+                const int row = f / KQ, kq = f % KQ;
                 const int n = n0 + row, k = k0 + kq * 4;
                 okb[i] = n < g.N && k < g.K;
                 rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(n, g.N - 1) * g.ldb + min(k, g.K - 4));
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * 256, row = f >> 2, kq = f & 3;
+            const int f = tid + i * 256, row = f / KQ, kq = f % KQ;
             if (f >= A_F4) continue;
             float4 v = ra[i];
             if (A2) { v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w; }
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 const int kr = f / (BN / 4), nq = f % (BN / 4);
                 *reinterpret_cast<float4 *>(&Bs[buf][kr][nq * 4]) = v;
             } else {
-                const int row = f >> 2, kq = f & 3;
+                const int row = f / KQ, kq = f % KQ;
                 Bs[buf][kq * 4 + 0][row] = v.x;
                 Bs[buf][kq * 4 + 1][row] = v.y;
                 Bs[buf][kq * 4 + 2][row] = v.z;
@@ -199,14 +200,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 16>
 int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
 {
     const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch), block(256);
     if (b_is_kn)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, BK>), grid, block, 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, BK>), grid, block, 0, st, g);
     return dfx::check_launch("gemm_f32_kernel");
 }
 
@@ -227,22 +228,22 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
            M, N, K, relu};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // tile choice.  Small M / N pick the matching narrow tile.  Otherwise weigh the operand reuse of
-    // the 128 x 128 tile against how evenly the grid spreads over the 256 CUs (all workgroups are
-    // co-resident at these sizes, so a CU holding ceil(blocks/256) workgroups sets the time).
+    // tile choice.  Small M / N pick the matching narrow tile.
+    if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128
+        if (force[0] == '0') return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+        if (force[0] == '1') return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+        if (force[0] == '2') return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
+        if (force[0] == '3') return launch<64, 128, 1, 4, 32>(g, batch, b_is_kn, st);
+        if (force[0] == '4') return launch<128, 128, 2, 2, 32>(g, batch, b_is_kn, st);
+    }
     if (M <= 64) return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
     if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
     if (N <= 64) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
     if (N <= 96) return launch<128, 96, 4, 1>(g, batch, b_is_kn, st);
-    auto balance = [&](int bm, int bn) {
-        const double blocks = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
-        const double per_cu = blocks / 256.0;
-        const double fill = per_cu / (double)(long)(per_cu + 0.999999);      // 1.0 = perfectly even
-        const double edge = ((double)M * N) / ((double)((M + bm - 1) / bm * bm) * ((N + bn - 1) / bn * bn));
-        return fill * edge;
-    };
-    const double s128 = balance(128, 128), s64n = 0.90 * balance(128, 64), s64m = 0.90 * balance(64, 128);
-    if (s128 >= s64n && s128 >= s64m) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
-    if (s64n >= s64m) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+    // Measured on the path's shapes (tools/bench_gemm.py with DFX_GEMM_TILE): all tiles land within
+    // ~10 % of each other (the kernel is paced by the matrix pipe at the clock the chip holds, not by
+    // operand reuse), and the 64 x 128 tile - 6 waves per SIMD - is the most even performer; the
+    // 128 x 128 tile is kept for the large, deep convolutions of layer4 where it is 2-3 % ahead.
+    if (M >= 1024 && (long)N * batch >= 16384 && K >= 512 && K <= 1024) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }
