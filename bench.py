@@ -15,8 +15,9 @@ Inputs are resident in HBM before the timed region.  Compute type fp32 throughou
 The JSON line also carries
   roofline     the MSDA forward kernel at the encoder geometry (N = frames per micro-batch,
                Lq = S = 4200, L = 1): algorithmic bytes 4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per
-               launch over the mean launch time, measured with HIP events recorded on the launch
-               stream inside the timed steps; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
+               launch over the mean kernel duration of those launches inside the timed steps, taken
+               from HIP events that the launch itself stamps on its stream (hipExtLaunchKernelGGL);
+               peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
                (a 2-frame clip at full resolution) on the box's host cores.
@@ -139,13 +140,13 @@ def main():
     for _ in range(a.warmup):
         runner(mine)
     barrier()
-    ops.PROFILE = []                                               # HIP events around encoder-shape MSDA launches
+    ops.profile_start()                                            # MSDA kernels stamp their own begin/end events
     t0 = time.perf_counter()
     for _ in range(a.steps):
         runner(mine)
     barrier()
     dt = time.perf_counter() - t0
-    events, ops.PROFILE = ops.PROFILE, None
+    launches = ops.profile_stop()
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -154,7 +155,7 @@ def main():
 
     if rank == 0:
         fps = a.frames * a.steps / dt
-        enc = [(e0.elapsed_time(e1) * 1e-3, nbytes) for (e0, e1, nbytes, lq, s) in events if lq == s]
+        enc = [(sec, nbytes) for (sec, nbytes, lq, s) in launches if lq == s and sec > 0]
         roof = None
         if enc:
             mean_t = sum(x for x, _ in enc) / len(enc)

@@ -1,9 +1,12 @@
 // Shared host/device helpers of the gfx950 kernels (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
+#include <vector>
 
 #include "dfx_msda.h"
 
@@ -46,6 +49,45 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk)
 }
 
 constexpr int kWave = 64;
+
+// ---- optional per-launch timing -----------------------------------------------------------
+// Measurement aid for bench.py (include/dfx_msda.h, dfx_profile_*).  While enabled, kernels launched
+// through launch_timed() are dispatched with hipExtLaunchKernelGGL, which stamps a (start, stop) event
+// pair with the kernel's own begin / end timestamps - the kernel duration proper, without the
+// dispatch gap a pair of hipEventRecord calls around the launch would include.  The pairs are kept in
+// a process-wide list until dfx_profile_drain() reads and destroys them.
+struct ProfileRecord {
+    hipEvent_t start, stop;
+    long bytes;
+    int tag_a, tag_b;
+};
+struct ProfileState {
+    bool enabled = false;
+    std::mutex mu;
+    std::vector<ProfileRecord> records;
+};
+inline ProfileState &profile_state()
+{
+    static ProfileState s;
+    return s;
+}
+
+template <typename Kernel, typename... Args>
+inline void launch_timed(long bytes, int tag_a, int tag_b, Kernel kernel, dim3 grid, dim3 block, size_t lds,
+                         hipStream_t st, Args... args)
+{
+    ProfileState &p = profile_state();
+    if (p.enabled) {
+        ProfileRecord r{nullptr, nullptr, bytes, tag_a, tag_b};
+        if (hipEventCreate(&r.start) == hipSuccess && hipEventCreate(&r.stop) == hipSuccess) {
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, r.start, r.stop, 0, args...);
+            std::lock_guard<std::mutex> lock(p.mu);
+            p.records.push_back(r);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
 
 // ---- argument checks shared by every MSDA entry point ------------------------------------
 // returns <0: error code, 1: empty problem (nothing to launch), 0: go

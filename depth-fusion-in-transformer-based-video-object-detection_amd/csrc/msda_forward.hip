@@ -323,5 +323,34 @@ extern "C" int dfx_msda_forward_f64(const double *value, const int64_t *shapes, 
     return dfx::check_launch("msda_fwd_generic<double>");
 }
 
-extern "C" int dfx_abi_version(void) { return 1; }
+extern "C" int dfx_abi_version(void) { return 2; }
+
+extern "C" int dfx_profile_enable(int on)
+{
+    dfx::profile_state().enabled = on != 0;
+    return DFX_OK;
+}
+
+extern "C" int dfx_profile_drain(float *ms, long *bytes, int *tag_a, int *tag_b, int cap)
+{
+    dfx::ProfileState &p = dfx::profile_state();
+    std::lock_guard<std::mutex> lock(p.mu);
+    int n = 0;
+    for (auto &r : p.records) {
+        float t = -1.f;
+        if (hipEventSynchronize(r.stop) == hipSuccess) (void)hipEventElapsedTime(&t, r.start, r.stop);
+        if (n < cap) {
+            if (ms) ms[n] = t;
+            if (bytes) bytes[n] = r.bytes;
+            if (tag_a) tag_a[n] = r.tag_a;
+            if (tag_b) tag_b[n] = r.tag_b;
+            ++n;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    p.records.clear();
+    return n;
+}
+
 extern "C" const char *dfx_last_error(void) { return dfx::err_slot(); }

@@ -148,12 +148,14 @@ int launch(int ref_dim, const float *value, const int64_t *shapes, const int64_t
     int iters = 1;
     while (iters < 8 && NQ / (8L * iters * 2) >= 2048) iters *= 2;
     const dim3 grid((unsigned)((NQ + 8L * iters - 1) / (8L * iters))), block(256);
+    // algorithmic bytes of this launch: value + (offsets, logits) + out, fp32
+    const long bytes = 4L * ((long)(NQ / Lq) * S * 256 + 3L * NQ * 8 * LT * 4 + (long)NQ * 256);
     if (ref_dim == 2)
-        hipLaunchKernelGGL((msda_fused_taps<LT, 2>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
-                           off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
+        dfx::launch_timed(bytes, Lq, S, msda_fused_taps<LT, 2>, grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
+                          off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
     else
-        hipLaunchKernelGGL((msda_fused_taps<LT, 4>), grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
-                           off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
+        dfx::launch_timed(bytes, Lq, S, msda_fused_taps<LT, 4>, grid, block, 0, st, value, shapes, lsi, ref, Lr, off,
+                          off_stride, logits, logit_stride, NQ, Lq, S, iters, out);
     return dfx::check_launch("msda_fused_taps");
 }
 

@@ -18,9 +18,24 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # samples stay inside the staged halo and loses otherwise, so it is opt-in.
 USE_TILE_KERNEL = os.environ.get("DFX_MSDA_TILE", "0") == "1"
 
-# Measurement hook (bench.py): when set to a list, every fused MSDA launch is bracketed by two
-# HIP events recorded on the launch stream and (start, end, algorithmic_bytes, Lq, S) is appended.
-PROFILE = None
+# Measurement hook (bench.py): profile_start() makes every fused MSDA kernel stamp its own begin / end
+# timestamps (include/dfx_msda.h, dfx_profile_*); profile_stop() returns [(seconds, algorithmic_bytes,
+# Lq, S), ...] for the launches in between.
+def profile_start():
+    _lib.load().dfx_profile_enable(1)
+
+
+def profile_stop(cap=65536):
+    import ctypes
+    lib = _lib.load()
+    lib.dfx_profile_enable(0)
+    ms = (ctypes.c_float * cap)()
+    nb = (ctypes.c_long * cap)()
+    lq = (ctypes.c_int * cap)()
+    s = (ctypes.c_int * cap)()
+    n = lib.dfx_profile_drain(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p),
+                              ctypes.cast(lq, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), cap)
+    return [(ms[i] * 1e-3, nb[i], lq[i], s[i]) for i in range(n)]
 
 
 def _require(cond, msg):
@@ -131,10 +146,6 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     _require(reference_points.dtype == torch.float32 and reference_points.shape[0] == N, "bad reference_points")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     base = qproj.data_ptr()
-    prof = PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(value.device))
     host = getattr(spatial_shapes, "_dfx_host", None)
     tile = USE_TILE_KERNEL and host is not None and L == 1 and Lr == 1 and Lq == S == host[0][0] * host[0][1]
     with torch.cuda.device(value.device):
@@ -148,9 +159,6 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
                 reference_points.data_ptr(), ref_dim, Lr,
                 base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
                 N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
-    if prof is not None:
-        e1.record(torch.cuda.current_stream(value.device))
-        prof.append((e0, e1, 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D), Lq, S))
     _lib.check(rc, "msda_fused_forward")
     return out
 

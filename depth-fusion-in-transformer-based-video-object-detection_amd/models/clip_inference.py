@@ -38,6 +38,12 @@ class ClipRunner:
         if fused is None:
             fused = next(model.parameters()).is_cuda
         enable_fused_inference(model, fused)
+        self._const = {}       # small index tensors, built once (each build is a blocking H2D copy)
+
+    def _cached(self, key, build):
+        if key not in self._const:
+            self._const[key] = build()
+        return self._const[key]
 
     # ---- steps 1+2 for a block of frames -------------------------------------------------------
     @torch.no_grad()
@@ -46,8 +52,10 @@ class ClipRunner:
         m, tr = self.model, self.model.transformer
         F_, _, H, W = frames.shape
         if mask is None:
-            mask = torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device)
-        whwh = torch.as_tensor((W, H, W, H), dtype=torch.long, device=frames.device).repeat(1, m.num_queries, 1)
+            mask = self._cached(("mask", F_, H, W, str(frames.device)),
+                                lambda: torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device))
+        whwh = self._cached(("whwh", W, H, str(frames.device)), lambda: torch.as_tensor(
+            (W, H, W, H), dtype=torch.long, device=frames.device).repeat(1, m.num_queries, 1))
         keep = {k: [] for k in ("cur", "ref", "logits", "ref_last", "memory")}
         meta = None
         for s in range(0, F_, self.micro_batch):
@@ -91,8 +99,9 @@ class ClipRunner:
         T = all_ref.shape[0]
         F_ = local["cur"].shape[0]
         dev = all_ref.device
-        others = torch.as_tensor([[j for j in range(T) if j != first_frame + i] for i in range(F_)],
-                                 dtype=torch.long, device=dev)                     # [F, T-1], clip order
+        others = self._cached(("others", T, first_frame, F_, str(dev)), lambda: torch.as_tensor(
+            [[j for j in range(T) if j != first_frame + i] for i in range(F_)],
+            dtype=torch.long, device=dev))                                         # [F, T-1], clip order
         final_hs, final_refs, _, picks = tr.temporal_stage(
             local["cur"], local["ref_last"], local["memory"], all_ref, all_logits, others,
             local["spatial_shapes"], local["level_start_index"], local["valid_ratios"],

@@ -37,10 +37,19 @@ def _add_pos(x, pos):
 
 
 # ---- level bookkeeping: device tensors for the kernels, host copies for Python loops -------------
+_LEVEL_CACHE = {}
+
+
 def make_level_tensors(shape_list, device):
     """(spatial_shapes i64 [L,2], level_start_index i64 [L]) on ``device`` from host (H,W) pairs.
-    The host list rides along (``_dfx_host``) so later code never reads sizes back from the GPU."""
+    The host list rides along (``_dfx_host``) so later code never reads sizes back from the GPU, and
+    the pair is cached per (shapes, device): building it is a blocking host-to-device copy, i.e. a
+    full stream synchronisation per forward if done every time."""
     shape_list = [(int(h), int(w)) for h, w in shape_list]
+    key = (tuple(shape_list), str(device))
+    hit = _LEVEL_CACHE.get(key)
+    if hit is not None:
+        return hit
     starts, acc = [], 0
     for h, w in shape_list:
         starts.append(acc)
@@ -49,6 +58,9 @@ def make_level_tensors(shape_list, device):
     lsi = torch.as_tensor(starts, dtype=torch.long, device=device)
     shapes._dfx_host = shape_list
     shapes._dfx_tokens = acc
+    if len(_LEVEL_CACHE) > 64:
+        _LEVEL_CACHE.clear()
+    _LEVEL_CACHE[key] = (shapes, lsi)
     return shapes, lsi
 
 

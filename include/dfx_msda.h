@@ -51,6 +51,17 @@ int dfx_abi_version(void);
 const char *dfx_last_error(void);
 
 /*
+ * Measurement aid (bench.py); not part of the reference's surface and the one place with process-wide
+ * state.  While enabled, every fused MSDA kernel is dispatched with hipExtLaunchKernelGGL, which stamps
+ * an event pair with the kernel's own begin / end timestamps (the kernel duration proper, on the launch
+ * stream, without the dispatch gap of hipEventRecord pairs).  dfx_profile_drain waits for the recorded
+ * kernels, writes up to `cap` records (duration in ms, algorithmic bytes of the launch, Lq, S), frees the
+ * events and returns the number written.
+ */
+int dfx_profile_enable(int on);
+int dfx_profile_drain(float *ms, long *bytes, int *lq, int *s, int cap);
+
+/*
  * Forward: out[b,q,m,c] = sum_{l,p} aw[b,q,m,l,p] * bilinear(value_l[b,:,m,c], x*W_l-0.5, y*H_l-0.5)
  * Replaces ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:20-80) and the
  * kernel ms_deformable_im2col_gpu_kernel (ms_deform_im2col_cuda.cuh:237-299).
