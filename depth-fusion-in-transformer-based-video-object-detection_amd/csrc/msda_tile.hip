@@ -24,6 +24,7 @@
 // of the block index, so under the round-robin XCD placement each XCD's L2 sees one head's
 // 128-byte column of the value rows.
 #include "dfx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -58,25 +59,26 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
     const long S = (long)H * W;
     const float *vb = value + (long)b * S * 256 + h * 32;      // this frame, this head
 
-    // ---- stage the window: 8 threads per position, 32 positions per pass, 6 passes in flight ----
+    // ---- stage the window: 8 threads per position, 32 positions per pass; ALL passes (<= 20, the
+    //      window is capped at 640 positions) are issued before the first LDS store, so a workgroup
+    //      pays one memory round trip for its window, not one per pass ----
     {
         const int c = tid & 7;
         const int npos = WH * WW;
-        for (int base = tid >> 3; base < npos; base += 32 * 6) {
-            float4 v[6];
+        constexpr int PASSES = 20;
+        float4 v[PASSES];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int ip = base + u * 32;
-                const int py = wy0 + ip / WW, px = wx0 + ip % WW;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ip < npos && py >= 0 && py < H && px >= 0 && px < W)
-                    v[u] = *reinterpret_cast<const float4 *>(vb + ((long)py * W + px) * 256 + c * 4);
-            }
+        for (int u = 0; u < PASSES; ++u) {
+            const int ip = (tid >> 3) + u * 32;
+            const int py = wy0 + ip / WW, px = wx0 + ip % WW;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ip < npos && py >= 0 && py < H && px >= 0 && px < W)
+                v[u] = *reinterpret_cast<const float4 *>(vb + ((long)py * W + px) * 256 + c * 4);
+        }
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int ip = base + u * 32;
-                if (ip < npos) win[ip * 8 + ((c + (ip >> 1)) & 7)] = v[u];
-            }
+        for (int u = 0; u < PASSES; ++u) {
+            const int ip = (tid >> 3) + u * 32;
+            if (ip < npos) win[ip * 8 + ((c + (ip >> 1)) & 7)] = v[u];
         }
     }
     __syncthreads();
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void msda_fused_tile(const float *__restric
 }
 
 // tile shape: maximise (queries actually covered / threads) x (tile area / window area)
-void pick_tile(int H, int W, int &TH, int &TW)
+void pick_tile(int H, int W, int &TH, int &TW, long cap_bytes)
 {
     double best = -1.0;
     TH = 8; TW = 32;
@@ -195,7 +197,7 @@ void pick_tile(int H, int W, int &TH, int &TW)
         if (tw > W) tw = W;
         if (tw < 4) continue;
         const long win_bytes = (long)(th + HALO_LO + HALO_HI) * (tw + HALO_LO + HALO_HI) * 128;
-        if (win_bytes > 80 * 1024) continue;                    // two workgroups per CU
+        if (win_bytes > cap_bytes) continue;
         const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
         const double util = (double)H * W / ((double)ty * tx * 256.0);
         const double reuse = (double)th * tw / ((double)(th + 9) * (tw + 9));
@@ -207,7 +209,7 @@ void pick_tile(int H, int W, int &TH, int &TW)
         if (W % tw) continue;
         for (int th = 4; th <= 32 && th * tw <= 256; ++th) {
             const long win_bytes = (long)(th + 9) * (tw + 9) * 128;
-            if (win_bytes > 80 * 1024) continue;
+            if (win_bytes > cap_bytes) continue;
             const int ty = (H + th - 1) / th, tx = W / tw;
             const double util = (double)H * W / ((double)ty * tx * 256.0);
             const double reuse = (double)th * tw / ((double)(th + 9) * (tw + 9));
@@ -233,7 +235,9 @@ extern "C" int dfx_msda_fused_tile_forward_f32(const float *value, const float *
         return dfx::fail(DFX_EINVAL, "msda tile: buffers must be 16-byte aligned");
     if ((long)N * H * W >= (1L << 28)) return dfx::fail(DFX_ERANGE, "msda tile: too many queries");
     int TH, TW;
-    pick_tile(H, W, TH, TW);
+    const char *cap_env = getenv("DFX_TILE_LDS_KB");
+    const long cap = (cap_env ? atol(cap_env) : 80) * 1024;
+    pick_tile(H, W, TH, TW, cap);
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const long blocks = (long)N * tiles_x * tiles_y * 8;
     if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "msda tile: grid too large");
