@@ -38,7 +38,127 @@ __global__ __launch_bounds__(256) void bias_act_nchw(const float *__restrict__ x
     }
 }
 
+// residual add + LayerNorm: one wave per row, the row lives in registers (<= 4 float4 per lane),
+// mean and variance by two in-register passes + xor-shuffle reductions (same formula as
+// nn.LayerNorm: biased variance, eps under the square root).
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void add_layernorm(const float *__restrict__ x, const float *__restrict__ res,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     float *__restrict__ out, long rows, int C, float eps)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float4 v[CHUNKS];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+        const int c = k * 256 + lane * 4;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            v[k] = *reinterpret_cast<const float4 *>(x + row * C + c);
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4 *>(res + row * C + c);
+                v[k].x += r.x; v[k].y += r.y; v[k].z += r.z; v[k].w += r.w;
+            }
+            sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+        if (k * 256 + lane * 4 < C) {
+            const float a = v[k].x - mean, b = v[k].y - mean, c2 = v[k].z - mean, d = v[k].w - mean;
+            sq += (a * a + b * b) + (c2 * c2 + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < C) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+            float4 o;
+            o.x = (v[k].x - mean) * rstd * g.x + b.x;
+            o.y = (v[k].y - mean) * rstd * g.y + b.y;
+            o.z = (v[k].z - mean) * rstd * g.z + b.z;
+            o.w = (v[k].w - mean) * rstd * g.w + b.w;
+            *reinterpret_cast<float4 *>(out + row * C + c) = o;
+        }
+    }
+}
+
+// stem epilogue: relu and +bias are monotonic, so relu(max(window) + b) == max(relu(window + b)).
+// One output row of one (image, channel) plane per workgroup pass; the 3 input rows it needs are read
+// through L1 (neighbouring outputs share 1-2 of their 3 columns).
+__global__ __launch_bounds__(256) void bias_relu_maxpool(const float *__restrict__ x, const float *__restrict__ bias,
+                                                         float *__restrict__ out, int C, int H, int W, int Ho, int Wo,
+                                                         long rows)
+{
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int oy = (int)(row % Ho);
+        const long plane = row / Ho;
+        const float b = bias[plane % C];
+        const float *src = x + plane * H * W;
+        const int y0 = oy * 2 - 1;
+        for (int ox = threadIdx.x; ox < Wo; ox += blockDim.x) {
+            const int x0 = ox * 2 - 1;
+            float m = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y0 + dy;
+                if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = x0 + dx;
+                    if (xx >= 0 && xx < W) m = fmaxf(m, src[(long)yy * W + xx]);
+                }
+            }
+            out[row * Wo + ox] = fmaxf(m + b, 0.f);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int dfx_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int N, int C, int H, int W,
+                                         void *stream)
+{
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0) return dfx::fail(DFX_EINVAL, "bias_relu_maxpool: bad dimension");
+    if (N == 0) return DFX_OK;
+    if (!x || !bias || !out) return dfx::fail(DFX_EINVAL, "bias_relu_maxpool: null pointer");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3) / 2) + 1
+    const long rows = (long)N * C * Ho;
+    const unsigned grid = (unsigned)(rows < (1L << 20) ? rows : (1L << 20));
+    hipLaunchKernelGGL(bias_relu_maxpool, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, out, C, H,
+                       W, Ho, Wo, rows);
+    return dfx::check_launch("bias_relu_maxpool");
+}
+
+extern "C" int dfx_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,
+                                     float *out, long rows, int C, float eps, void *stream)
+{
+    if (rows < 0 || C <= 0) return dfx::fail(DFX_EINVAL, "add_layernorm: bad dimension");
+    if (rows == 0) return DFX_OK;
+    if (!x || !gamma || !beta || !out) return dfx::fail(DFX_EINVAL, "add_layernorm: null pointer");
+    if ((C & 3) || C > 1024 || !dfx::aligned16(x) || !dfx::aligned16(out) || !dfx::aligned16(gamma) ||
+        !dfx::aligned16(beta) || (res && !dfx::aligned16(res)))
+        return dfx::fail(DFX_EINVAL, "add_layernorm: C must be a multiple of 4 and <= 1024, buffers 16-byte aligned");
+    if ((rows + 3) / 4 >= (1L << 31)) return dfx::fail(DFX_ERANGE, "add_layernorm: too many rows");
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int chunks = (C + 255) / 256;
+    if (chunks == 1) hipLaunchKernelGGL(add_layernorm<1>, grid, block, 0, st, x, res, gamma, beta, out, rows, C, eps);
+    else if (chunks == 2) hipLaunchKernelGGL(add_layernorm<2>, grid, block, 0, st, x, res, gamma, beta, out, rows, C, eps);
+    else hipLaunchKernelGGL(add_layernorm<4>, grid, block, 0, st, x, res, gamma, beta, out, rows, C, eps);
+    return dfx::check_launch("add_layernorm");
+}
 
 extern "C" int dfx_bias_act_nchw_f32(const float *x, const float *bias, const float *residual, float *out, int N,
                                      int C, long HW, int relu, void *stream)

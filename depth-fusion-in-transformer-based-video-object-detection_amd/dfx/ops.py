@@ -272,3 +272,38 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
                               int(bool(relu)), _stream(x.device))
     _lib.check(rc, "conv1x1")
     return out
+
+
+def add_layernorm(x, residual, norm):
+    """``norm(x + residual)`` for an nn.LayerNorm over the last dimension, in one pass
+    (include/dfx_fused.h); residual may be None."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    x2 = x.contiguous()
+    named = [("x", x2), ("weight", norm.weight), ("bias", norm.bias)]
+    if residual is not None:
+        residual = residual.contiguous()
+        named.append(("residual", residual))
+        _require(residual.shape == x2.shape, "residual must match x")
+    _check_inputs(named)
+    _require(x2.dtype == torch.float32 and norm.weight.numel() == C, "add_layernorm: fp32, LayerNorm over the last dim")
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x2.device):
+        rc = lib.dfx_add_layernorm_f32(x2.data_ptr(), _ptr(residual), norm.weight.data_ptr(), norm.bias.data_ptr(),
+                                       out.data_ptr(), x2.numel() // C, C, float(norm.eps), _stream(x2.device))
+    _lib.check(rc, "add_layernorm")
+    return out
+
+
+def bias_relu_maxpool(x, bias):
+    """maxpool3x3/s2/p1(relu(x + bias[c])) on NCHW in one pass: the ResNet stem's epilogue
+    (include/dfx_fused.h)."""
+    lib = _lib.load()
+    _check_inputs([("x", x), ("bias", bias)])
+    _require(x.dtype == torch.float32 and x.dim() == 4 and bias.numel() == x.shape[1], "bias_relu_maxpool: fp32 NCHW")
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dfx_bias_relu_maxpool_f32(x.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, H, W, _stream(x.device))
+    _lib.check(rc, "bias_relu_maxpool")
+    return out

@@ -127,7 +127,7 @@ class ResNet50(nn.Module):
         if getattr(self, "_stem_folded", None) is None or self._stem_folded[0] != key:
             self._stem_folded = (key, _fold(self.conv1, self.bn1))
         w, b = self._stem_folded[1]
-        return self.maxpool(_ops.bias_act_(F.conv2d(x, w, None, 2, 3), b, relu=True))
+        return _ops.bias_relu_maxpool(F.conv2d(x.contiguous(), w, None, 2, 3), b)
 
     def run_stage(self, stage, x, fused=False):
         if not fused:

@@ -36,6 +36,16 @@ def _add_pos(x, pos):
     return x if pos is None else x + pos
 
 
+def _norm_add(norm, x, y=None):
+    """norm(x + y).  Inference on the GPU: one fused pass (dfx.ops.add_layernorm); otherwise the
+    reference's two ops."""
+    if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 4 == 0 \
+            and x.shape[-1] <= 1024:
+        from dfx import ops as _ops
+        return _ops.add_layernorm(x, y, norm)
+    return norm(x if y is None else x + y)
+
+
 # ---- level bookkeeping: device tensors for the kernels, host copies for Python loops -------------
 _LEVEL_CACHE = {}
 
@@ -110,7 +120,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         y = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(y))
+        return _norm_add(self.norm2, src, self.dropout3(y))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
                 rgbd_src=None):
@@ -122,11 +132,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
         else:
             query = _add_pos(src, pos)
         y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        src = self.norm1(src + self.dropout1(y))
+        src = _norm_add(self.norm1, src, self.dropout1(y))
         if fused and self.activation is F.relu and src.shape[0] * src.shape[1] >= 2048:
             from dfx import ops as _ops            # linear1 + bias + ReLU in one MFMA GEMM
             h = _ops.linear(src.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
-            return self.norm2(src + self.linear2(h))
+            return _norm_add(self.norm2, src, self.linear2(h))
         return self.forward_ffn(src)
 
 
@@ -175,13 +185,14 @@ class _CrossFusionBlock(nn.Module):
 
     def forward_ffn(self, tgt):
         y = self.activation(self.linear1(tgt))
-        return getattr(self, self._ffn_norm)(tgt + getattr(self, self._ffn_drop)(y))
+        return _norm_add(getattr(self, self._ffn_norm), tgt, getattr(self, self._ffn_drop)(y))
 
     def _fuse(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask):
-        src = self.norm_depth_scale(self.depth_scale_adapt(src))
-        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                            src_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(self.cross_scale_adapt(y)))
+        src = _norm_add(self.norm_depth_scale, self.depth_scale_adapt(src))
+        fused = tgt.is_cuda and not torch.is_grad_enabled() and tgt.dtype == torch.float32 and query_pos is not None
+        query = (tgt, query_pos) if fused else _add_pos(tgt, query_pos)
+        y = self.cross_attn(query, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask)
+        tgt = _norm_add(self.norm1, tgt, self.dropout1(self.cross_scale_adapt(y)))
         return self.forward_ffn(tgt)
 
 
@@ -270,16 +281,16 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(y))
+        return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
         y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(y))
+        tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
         y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
                             level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(y))
+        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
         return self.forward_ffn(tgt)
 
 
@@ -366,16 +377,16 @@ class TemporalQueryEncoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(y))
+        return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
         qk = _add_pos(query, query_pos)
         y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), query.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm2(query + self.dropout2(y))
+        tgt = _norm_add(self.norm2, query, self.dropout2(y))
         y = self.cross_attn(_add_pos(tgt, query_pos).transpose(0, 1),
                             _add_pos(ref_query, ref_query_pos).transpose(0, 1),
                             ref_query.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm1(tgt + self.dropout1(y))
+        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
         return self.forward_ffn(tgt)
 
 
@@ -416,14 +427,14 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(y))
+        return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
         y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(y))
+        tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
         y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
                             frame_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(y))
+        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
         return self.forward_ffn(tgt)

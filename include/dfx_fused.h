@@ -22,6 +22,19 @@ extern "C" {
 int dfx_bias_act_nchw_f32(const float *x, const float *bias, const float *residual, float *out,
                           int N, int C, long HW, int relu, void *stream);
 
+/* ResNet stem epilogue in one pass: out = maxpool3x3/s2/p1( relu(x + bias[c]) ), NCHW.
+ * Replaces FrozenBatchNorm2d (shift; the scale is folded into conv1) + ReLU + nn.MaxPool2d of the stem
+ * (/root/reference/models/backbone_scratch.py:112-115).  x [N,C,H,W] -> out [N,C,(H+1)/2,(W+1)/2]. */
+int dfx_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int N, int C, int H, int W,
+                              void *stream);
+
+/* Residual add + LayerNorm over the last dimension in one pass (the reference runs ``norm(x + y)`` as an
+ * add kernel followed by nn.LayerNorm: deformable_transformer_single.py:556-562 and every other block):
+ *   out[r,:] = LayerNorm(x[r,:] (+ res[r,:])) * gamma + beta,  biased variance, eps inside the sqrt.
+ * x, res (may be NULL), out: [rows, C] packed fp32; C a multiple of 4, C <= 1024; out may alias x. */
+int dfx_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
+                          long rows, int C, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,27 @@ def test_conv1x1_matches_torch(Nb, Ci, Co, H, W):
         want2 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=2)
         got2 = ops.conv1x1(x, w, stride=2)
         assert (got2.double() - want2).abs().max().item() < 4e-6 * Ci ** 0.5
+
+
+@pytest.mark.parametrize("rows,C", [(4200, 256), (33, 64), (7, 1024), (300, 512), (5, 260)])
+def test_add_layernorm_matches_torch(rows, C):
+    from dfx import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 3 + 1).cuda()
+    r = torch.randn(rows, C, generator=g).cuda()
+    ln = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+        assert torch.allclose(ops.add_layernorm(x, r, ln), ln(x + r), atol=2e-5, rtol=1e-5)
+        assert torch.allclose(ops.add_layernorm(x, None, ln), ln(x), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 50, 67), (1, 3, 7, 9), (2, 5, 8, 8), (1, 2, 1, 1)])
+def test_stem_epilogue_matches_torch(shape):
+    from dfx import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).cuda()
+    b = torch.randn(shape[1], generator=g).cuda()
+    want = torch.nn.functional.max_pool2d((x + b.view(1, -1, 1, 1)).relu(), 3, 2, 1)
+    assert torch.equal(ops.bias_relu_maxpool(x, b), want)
