@@ -1,0 +1,70 @@
+"""GPU, 2 processes sharing cuda:0, gloo transport: the sharded clip path on the HIP kernels gives the
+same per-frame outputs as one process running the whole clip.  (RCCL itself needs one GPU per rank;
+the 8-GPU run is the driver's.  What is exercised here is everything around the transport: frame
+blocks per rank, the packed all-gather message, clip-order reassembly, the batched temporal stage.)"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd")
+
+
+def _build():
+    from models import build_model
+    from models.config import transvodpp_args
+    from tests._param_fill import fill_params_by_name
+    model, _, _ = build_model(transvodpp_args(num_ref_frames=3, device="cuda"))
+    fill_params_by_name(model, seed=5)
+    with torch.no_grad():
+        for h in list(model.bbox_embed) + list(model.temp_bbox_embed_list):
+            h.layers[-1].weight.mul_(0.2)
+    return model.cuda().eval()
+
+
+def _clip():
+    return torch.randn(4, 4, 64, 96, generator=torch.Generator().manual_seed(11))
+
+
+def _worker(rank, world, port, result_path):
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from models.clip_inference import ClipRunner
+        torch.cuda.set_device(0)
+        model = _build()
+        clip = _clip()
+        per = clip.shape[0] // world
+        out = ClipRunner(model, micro_batch=2)(clip[rank * per:(rank + 1) * per].cuda())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: out[k].cpu() for k in ("pred_logits", "pred_boxes")})
+        if rank == 0:
+            torch.save(gathered, result_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    result = str(tmp_path / "sharded.pt")
+    mp.spawn(_worker, args=(2, port, result), nprocs=2, join=True)
+    sharded = torch.load(result)
+    from models.clip_inference import ClipRunner
+    whole = ClipRunner(_build(), micro_batch=2)(_clip().cuda())
+    logits = torch.cat([s["pred_logits"] for s in sharded], 0)
+    boxes = torch.cat([s["pred_boxes"] for s in sharded], 0)
+    assert torch.allclose(logits, whole["pred_logits"].cpu(), atol=1e-5)
+    assert torch.allclose(boxes, whole["pred_boxes"].cpu(), atol=1e-5)
+    top_a = torch.topk(logits.sigmoid().view(4, -1), 100, dim=1)[1]
+    top_b = torch.topk(whole["pred_logits"].cpu().sigmoid().view(4, -1), 100, dim=1)[1]
+    assert torch.equal(top_a, top_b)
