@@ -22,6 +22,8 @@ SIGNATURES = {
     # include/dfx_roi.h: input, rois, N, C, H, W, K, ph, pw, scale, sampling_ratio, aligned, out, stream
     "dfx_roi_align_nchw_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
     "dfx_roi_align_nhwc_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
+    # include/dfx_preprocess.h
+    "dfx_preprocess_u8_f32": [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _p, _p],
     # include/dfx_gemm.h
     "dfx_gemm_f32": [_p, _p, _l, _l, _p, _l, _l, _i, _p, _i, _p, _l, _l, _p, _l, _p, _l, _l, _i, _i, _i, _i, _i, _p],
     # include/dfx_fused.h: x, bias, residual, out, N, C, HW, relu, stream
