@@ -151,3 +151,78 @@ def test_bias_act_kernel():
                 want = want.relu() if relu else want
                 got = ops.bias_act_(x.clone(), b, res, relu)
                 assert torch.allclose(got, want, atol=1e-6)
+
+
+def _cpu_ops():
+    import models.ops.functions.ms_deform_attn_func as f
+    from dfx import ops
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    saved = (f.MSDeformAttnFunction, ops.roi_align)
+    _patch_cpu_ops()
+    return f, ops, saved
+
+
+@pytest.mark.parametrize("fusion", ["Baseline", "LateFusion", "Encoder_CrossFusion"])
+def test_single_frame_configs_gpu_vs_cpu_oracle(fusion):
+    """BASELINE.json configs A-C: Deformable-DETR single frame (RGB / Late Fusion / Encoder Cross Fusion)
+    through build_model, padded batch of two different-size images (valid_ratio != 1 branches),
+    HIP path vs the same host code on CPU with the oracle operator; box indices of PostProcess."""
+    from models import build_model
+    from models.config import single_args
+    from models.fused import enable_fused_inference
+    from tests._param_fill import fill_params_by_name
+    from util.misc import nested_tensor_from_tensor_list
+    C = 3 if fusion == "Baseline" else 4
+    g = torch.Generator().manual_seed(9)
+    imgs = [torch.randn(C, 64, 96, generator=g), torch.randn(C, 48, 80, generator=g)]
+
+    def make(device):
+        model, _, post = build_model(single_args(fusion, device=device))
+        fill_params_by_name(model, seed=8)
+        with torch.no_grad():
+            for h in model.bbox_embed:
+                h.layers[-1].weight.mul_(0.2)
+        return model.to(device).eval(), post
+
+    gm, post = make("cuda")
+    enable_fused_inference(gm)
+    with torch.no_grad():
+        got = gm(nested_tensor_from_tensor_list([i.cuda() for i in imgs]))
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = make("cpu")
+        with torch.no_grad():
+            want = cm(nested_tensor_from_tensor_list(imgs))
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    lg, bx = got["pred_logits"].cpu(), got["pred_boxes"].cpu()
+    assert lg.shape == (2, 300, 3)
+    assert (lg - want["pred_logits"]).abs().max() < 1e-3 and (bx - want["pred_boxes"]).abs().max() < 1e-3
+    sizes = torch.tensor([[64, 96], [48, 80]])
+    for rg, rc in zip(post["bbox"]({"pred_logits": lg, "pred_boxes": bx}, sizes), post["bbox"](want, sizes)):
+        margin = (rc["scores"][:-1] - rc["scores"][1:]).abs()
+        safe = torch.ones(100, dtype=torch.bool)
+        safe[:-1] &= margin > 1e-5
+        safe[1:] &= margin > 1e-5
+        assert torch.equal(rg["labels"][safe], rc["labels"][safe])
+        assert torch.allclose(rg["boxes"][safe], rc["boxes"][safe], atol=0.2)
+
+
+def test_padded_clip_gpu_vs_cpu_oracle():
+    """A TransVOD++ clip whose frames carry real padding (mask != 0, valid ratios < 1)."""
+    from models.clip_inference import ClipRunner
+    clip = _clip(3, 33)
+    mask = torch.zeros(3, 64, 96, dtype=torch.bool)
+    mask[:, 56:, :] = True
+    mask[:, :, 80:] = True
+    clip = clip * (~mask)[:, None]
+    gm, _ = _build("cuda")
+    got = ClipRunner(gm.cuda(), micro_batch=3)(clip.cuda(), mask.cuda())
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = _build("cpu")
+        want = ClipRunner(cm, micro_batch=3)(clip, mask)
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    assert (got["pred_logits"].cpu() - want["pred_logits"]).abs().max() < 1e-3
+    assert (got["pred_boxes"].cpu() - want["pred_boxes"]).abs().max() < 1e-3
