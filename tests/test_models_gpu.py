@@ -209,7 +209,14 @@ def test_single_frame_configs_gpu_vs_cpu_oracle(fusion):
 
 
 def test_padded_clip_gpu_vs_cpu_oracle():
-    """A TransVOD++ clip whose frames carry real padding (mask != 0, valid ratios < 1)."""
+    """A TransVOD++ clip whose frames carry real padding (mask != 0, valid ratios < 1): the spatial stage
+    (backbones, Late Fusion, encoder, decoder, heads) on the HIP path vs the CPU oracle path.
+
+    Only quantities that do not read PADDED tokens are compared.  The sine positional embedding of a
+    fully padded row / column is sin(~1e6) (normalisation by eps, position_encoding.py:47-49), whose
+    value depends on the libm at hand; masked attention never looks at those tokens, but the
+    query/RoI fusion of the temporal stage pools RoIs over the whole map including them, so its output
+    on padded clips is device-dependent in the reference as well."""
     from models.clip_inference import ClipRunner
     clip = _clip(3, 33)
     mask = torch.zeros(3, 64, 96, dtype=torch.bool)
@@ -217,12 +224,15 @@ def test_padded_clip_gpu_vs_cpu_oracle():
     mask[:, :, 80:] = True
     clip = clip * (~mask)[:, None]
     gm, _ = _build("cuda")
-    got = ClipRunner(gm.cuda(), micro_batch=3)(clip.cuda(), mask.cuda())
+    got = ClipRunner(gm.cuda(), micro_batch=3).frames_forward(clip.cuda(), mask.cuda())
     f, ops, saved = _cpu_ops()
     try:
         cm, _ = _build("cpu")
-        want = ClipRunner(cm, micro_batch=3)(clip, mask)
+        want = ClipRunner(cm, micro_batch=3).frames_forward(clip, mask)
     finally:
         f.MSDeformAttnFunction, ops.roi_align = saved
-    assert (got["pred_logits"].cpu() - want["pred_logits"]).abs().max() < 1e-3
-    assert (got["pred_boxes"].cpu() - want["pred_boxes"]).abs().max() < 1e-3
+    assert (got["logits"].cpu() - want["logits"]).abs().max() < 1e-3
+    assert (got["ref_last"].cpu() - want["ref_last"]).abs().max() < 1e-3
+    valid = ~torch.nn.functional.interpolate(mask[None].float(), size=(4, 6)).bool()[0].flatten(1)      # stride-16 map
+    diff = (got["memory"].cpu() - want["memory"]).abs().max(-1)[0]
+    assert (diff * valid).max() < 1e-3
