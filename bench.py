@@ -20,7 +20,7 @@ The JSON line also carries
                peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
-               (a 2-frame clip at full resolution) on the box's host cores.
+               (one 8-frame clip at full resolution, ~10 s) on the box's host cores.
 """
 import argparse
 import json
@@ -61,7 +61,7 @@ def build(device, num_ref_frames):
     return model.to(device).eval()
 
 
-def cpu_baseline(height, width, threads, frames=2):
+def cpu_baseline(height, width, threads, frames=8):
     """The same host code on CPU tensors, the oracle as the MSDA / RoIAlign operator."""
     from oracle import msda_oracle
     import models.ops.functions.ms_deform_attn_func as f
