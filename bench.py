@@ -160,7 +160,7 @@ def main():
         if enc:
             mean_t = sum(x for x, _ in enc) / len(enc)
             nbytes = enc[0][1]
-            roof = {"bound": "hbm", "kernel": "msda_fused_taps<1,2> (encoder / late-fusion geometry)",
+            roof = {"bound": "hbm", "kernel": "msda_fused_level<2> (encoder / late-fusion geometry, level in LDS)",
                     "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
                     "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, per_rank)),

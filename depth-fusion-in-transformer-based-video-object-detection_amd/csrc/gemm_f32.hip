@@ -39,6 +39,9 @@ struct Args {
     float *C;
     long ldc, strideC;
     int M, N, K, relu;
+    int cblk;             // > 0: C is stored column-block-major, [ceil(N / cblk)][M][cblk] (include/dfx_gemm.h)
+    long cblk_stride;     // elements between column blocks (>= M * cblk)
+    long ablk_stride;     // > 0: A is K-block-major, [K / 4][M][4] with this many elements between blocks
 };
 
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             const int f = tid + i * 256, row = f / KQ, kq = f % KQ;
             const int m = m0 + row, k = k0 + kq * 4;
             oka[i] = m < g.M && k < g.K;
-            const long o = (long)min(m, g.M - 1) * g.lda + min(k, g.K - 4);
+            const int mc = min(m, g.M - 1), kc = min(k, g.K - 4);
+            const long o = g.ablk_stride > 0 ? (long)(kc >> 2) * g.ablk_stride + (long)mc * 4 : (long)mc * g.lda + kc;
             ra[i] = *reinterpret_cast<const float4 *>(A + o);
             if (A2) ra2[i] = *reinterpret_cast<const float4 *>(A2 + o);
         }
@@ -175,10 +179,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
     int ncol[NT];
     float bcolv[NT];
+    long coff[NT];                                     // element offset of the column inside a C row
+    const long rowmul = g.cblk > 0 ? (long)g.cblk : g.ldc;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         ncol[j] = n0 + wn * TN + j * 32 + c;
-        bcolv[j] = bcol ? g.bias[min(ncol[j], g.N - 1)] : 0.f;
+        const int nc = min(ncol[j], g.N - 1);
+        bcolv[j] = bcol ? g.bias[nc] : 0.f;
+        coff[j] = g.cblk > 0 ? (long)(nc / g.cblk) * g.cblk_stride + nc % g.cblk : (long)nc;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 if (R) v += R[(long)mc * g.ldr + min(ncol[j], g.N - 1)];
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (rz) v = 0.f;
-                if (m < g.M && ncol[j] < g.N) C[(long)m * g.ldc + ncol[j]] = v;
+                if (m < g.M && ncol[j] < g.N) C[(long)m * rowmul + coff[j]] = v;
             }
         }
     }
@@ -216,7 +224,8 @@ int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
 extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long strideA, const float *B, long ldb,
                             long strideB, int b_is_kn, const float *bias, int bias_per_row, const float *R,
                             long ldr, long strideR, const unsigned char *row_mask, long strideMask, float *C,
-                            long ldc, long strideC, int M, int N, int K, int batch, int relu, void *stream)
+                            long ldc, long strideC, int M, int N, int K, int batch, int relu, int c_block,
+                            long c_block_stride, long a_block_stride, void *stream)
 {
     if (M < 0 || N < 0 || K <= 0 || batch < 0) return dfx::fail(DFX_EINVAL, "gemm: bad dimension");
     if ((long)M * N * batch == 0) return DFX_OK;
@@ -225,8 +234,12 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         (A2 && !dfx::aligned16(A2)) || (b_is_kn && (N & 3)))
         return dfx::fail(DFX_EINVAL, "gemm: K (and N for [K,N] operands) must be multiples of 4, rows 16-byte aligned");
     if (batch > 65535) return dfx::fail(DFX_ERANGE, "gemm: batch too large");
+    if (c_block < 0 || (c_block > 0 && (c_block_stride < (long)M * c_block || R)))
+        return dfx::fail(DFX_EINVAL, "gemm: column-block-major C needs c_block_stride >= M * c_block and no residual");
+    if (a_block_stride < 0 || (a_block_stride > 0 && (a_block_stride < (long)M * 4 || (a_block_stride & 3) || A2)))
+        return dfx::fail(DFX_EINVAL, "gemm: K-block-major A needs a_block_stride >= 4 * M (a multiple of 4) and no A2");
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
-           M, N, K, relu};
+           M, N, K, relu, c_block, c_block_stride, a_block_stride};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // tile choice.  Small M / N pick the matching narrow tile.
     if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128

@@ -1,0 +1,333 @@
+// Fused MSDA with the whole value level resident in LDS (gfx950), for single-level attention.
+//
+// Geometry: L = 1, M = 8, D = 32, P = 4 - the encoder self-attention, Late Fusion, Encoder Cross
+// Fusion and the backbone fusion block of the TransVOD++ RGB-D configuration (one H x W map at
+// stride 16: 50 x 84 = 4200 tokens at 800 x 1333).  The wave-per-query kernel (msda_fused.hip)
+// fetches every bilinear corner from L2: PMC counters show ~550 MB of L2 requests per 8-frame
+// launch for 82 MB of algorithmic traffic, so it runs at the L2 gather rate (~21 TB/s), 0.39 of
+// the HBM roofline.  Here the gathers are served by LDS (256 B/clk/CU, ~150 TB/s chip-wide):
+//
+//   workgroup = (frame, head, channel octet): 8 of the head's 32 channels of EVERY token of the
+//               level - (H+3) x (W+2) x 32 B with a zero border, 146 KB of the CU's 160 KB LDS for
+//               50 x 84 - staged once with 16-byte loads (each 128-byte value row is read by the
+//               4 octet-workgroups of its head, which the block order puts on the same XCD/L2);
+//   thread    = one query at a time (1024 threads, queries strided): softmax of the head's 4
+//               logits, 4 sampling locations, then 16 corners x 2 ds_read_b128 from LDS and 128
+//               FMAs into 8 accumulators; writes its 32 output bytes.
+//
+// LDS image: two planes of 16-byte chunks, plane c holding channels 4c..4c+3 of every bordered
+// token, so the 16 lanes of a ds_read_b128 group - neighbouring queries, neighbouring tokens -
+// read 16 consecutive 16-byte slots = all 64 banks once.  The zero border (one token on every
+// side) stands for the out-of-map corners of the reference's bilinear rule
+// (ms_deform_im2col_cuda.cuh:33-84), so a corner needs no bounds test: the sample-level skip rule
+// (-1 < h < H, -1 < w < W, :281-291) zeroes the attention weight instead.  Plane stride PL is
+// chosen = 4 mod 8 tokens so that a ds_write_b128 group of the staging pass (4 tokens x 2 planes)
+// covers 32 distinct banks.
+//
+// The tap arithmetic (softmax, location, bilinear weights) is repeated by the 4 octet-workgroups
+// of a head; that is the price of fitting the level into LDS, and it overlaps the staging loads of
+// the first iteration.  Levels that do not fit (more than ~5100 bordered tokens) and launches
+// with few queries per frame (decoder cross-attention, Lq = 300) stay on msda_fused.hip.
+#include "dfx_common.h"
+
+namespace {
+
+constexpr int THREADS = 1024;
+constexpr int STAGE_PASSES = 10;          // 2 chunks x 5120 tokens / 1024 threads: the LDS cap
+constexpr long LDS_CAP = 160 * 1024;
+
+typedef float v2f __attribute__((ext_vector_type(2)));      // v_pk_{mul,add,fma}_f32 operands
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+
+struct Taps {
+    int tb[4];          // bordered token index of corner (y0, x0) of each point
+    v2f wt[4], wb[4];   // corner weights {(y0,x0), (y0,x1)} and {(y1,x0), (y1,x1)}, attention weight folded in
+};
+
+// The Linear outputs of one (query, head) as loaded: 4 logits, 4 (x, y) offsets, the reference point.
+struct Raw {
+    float4 lg, o01, o23, r;
+};
+
+template <int REFDIM>
+__device__ __forceinline__ Raw load_raw(const float *__restrict__ rp, const float *__restrict__ op,
+                                        const float *__restrict__ lp)
+{
+    Raw w;
+    w.lg = *reinterpret_cast<const float4 *>(lp);
+    w.o01 = *reinterpret_cast<const float4 *>(op);
+    w.o23 = *reinterpret_cast<const float4 *>(op + 4);
+    if (REFDIM == 2) {
+        const float2 r = *reinterpret_cast<const float2 *>(rp);
+        w.r = make_float4(r.x, r.y, 0.f, 0.f);
+    } else {
+        w.r = *reinterpret_cast<const float4 *>(rp);
+    }
+    return w;
+}
+
+// exp(x) for x <= 0 (logit - max), two at a time: 2^(x*log2e) with the product's low part carried
+// (1 ulp, like libm's expf), without the overflow / denormal branches (x is clamped at -87).
+__device__ __forceinline__ v2f exp_neg(v2f x)
+{
+    x.x = fmaxf(x.x, -87.f);
+    x.y = fmaxf(x.y, -87.f);
+    const v2f L2E = splat(1.4426950216293335f), L2E_LO = splat(1.9259629911266175e-8f);
+    const v2f t = x * L2E;
+    v2f f = pk_fma(x, L2E, -t);
+    f = pk_fma(x, L2E_LO, f);
+    const v2f r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    const v2f a = (t - r) + f;
+    return (v2f){__builtin_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)r.x),
+                 __builtin_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)r.y)};
+}
+
+// Per-thread constants of the level.
+struct Level {
+    v2f size, rsize;    // (W, H) and their correctly rounded reciprocals
+    int H, W, WB;
+};
+
+// One (query, head): softmax over the 4 logits (F.softmax, ms_deform_attn.py:99), locations
+// ref + off / (W, H) or ref_xy + off / P * ref_wh * 0.5 (:102-110), pixel coordinates and bilinear
+// weights (ms_deform_im2col_cuda.cuh:33-84, :281-291).  Written on (x, y) pairs so that it compiles
+// to packed fp32 instructions; the two divisions per point are q = o*r, q += (o - q*size)*r with
+// r = RN(1/size), which is the correctly rounded quotient (Markstein), and the softmax quotient is
+// the same iteration on a Newton-refined v_rcp_f32.
+template <int REFDIM>
+__device__ __forceinline__ Taps make_taps(const Raw &in, const Level &lv)
+{
+    const float mx = fmaxf(fmaxf(in.lg.x, in.lg.y), fmaxf(in.lg.z, in.lg.w));
+    const v2f e01 = exp_neg((v2f){in.lg.x - mx, in.lg.y - mx});
+    const v2f e23 = exp_neg((v2f){in.lg.z - mx, in.lg.w - mx});
+    float sum = 0.f;
+    sum += e01.x; sum += e01.y; sum += e23.x; sum += e23.y;
+    float y0 = __builtin_amdgcn_rcpf(sum);
+    y0 = fmaf(fmaf(-sum, y0, 1.f), y0, y0);
+    const v2f ys = splat(y0), ss = splat(sum);
+    v2f a01 = e01 * ys, a23 = e23 * ys;
+    a01 = pk_fma(pk_fma(-a01, ss, e01), ys, a01);
+    a23 = pk_fma(pk_fma(-a23, ss, e23), ys, a23);
+    const float aw[4] = {a01.x, a01.y, a23.x, a23.y};
+    const v2f o[4] = {{in.o01.x, in.o01.y}, {in.o01.z, in.o01.w}, {in.o23.x, in.o23.y}, {in.o23.z, in.o23.w}};
+    const v2f rxy = {in.r.x, in.r.y}, rwh = {in.r.z, in.r.w};
+    Taps t;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        v2f loc;
+        if (REFDIM == 2) {
+            v2f q = o[p] * lv.rsize;
+            q = pk_fma(pk_fma(-q, lv.size, o[p]), lv.rsize, q);
+            loc = rxy + q;
+        } else {
+            loc = rxy + o[p] * splat(0.25f) * rwh * splat(0.5f);
+        }
+        const v2f im = pk_fma(loc, lv.size, splat(-0.5f));               // (w_im, h_im)
+        // clamp to [-1, size]: NaN and -inf land on -1 (zero border, weight 0), +inf on `size` (dropped below)
+        const float ws = __builtin_amdgcn_fmed3f(im.x, -1.f, lv.size.x);
+        const float hs = __builtin_amdgcn_fmed3f(im.y, -1.f, lv.size.y);
+        const float wf = floorf(ws), hf = floorf(hs);
+        const int ix = (int)wf, iy = (int)hf;
+        const v2f l = (v2f){ws, hs} - (v2f){wf, hf};                     // (lw, lh)
+        const v2f hc = splat(1.f) - l;                                   // (hw, hh)
+        // the skip rule -1 < h_im < H, -1 < w_im < W: a sample at exactly -1 has weight 0 on its only
+        // in-map row/column already, so only the upper bounds are left to test
+        const float aa = (iy < lv.H && ix < lv.W) ? aw[p] : 0.f;
+        const v2f xw = {hc.x, l.x};                                      // (hw, lw)
+        t.wt[p] = splat(hc.y) * xw * splat(aa);
+        t.wb[p] = splat(l.y) * xw * splat(aa);
+        t.tb[p] = (iy + 1) * lv.WB + ix + 1;                             // rows 0..H+1 (+1 more for y1)
+    }
+    return t;
+}
+
+__device__ __forceinline__ void fma4(float4 &a, float w, const float4 &v)
+{
+    a.x = fmaf(w, v.x, a.x);
+    a.y = fmaf(w, v.y, a.y);
+    a.z = fmaf(w, v.z, a.z);
+    a.w = fmaf(w, v.w, a.w);
+}
+
+// Operand strides (include/dfx_msda.h, dfx_msda_level_layout).  The reference layouts (value
+// [N,S,8,32], one row of Linear outputs per query, out [N,Lq,256]) work, but a workgroup then uses 32
+// of every 128-byte line it pulls from L2 and scatters its stores; the layouts the kernel is built for
+// are the block-major ones dfx_gemm_f32 writes / reads (c_block 4 and 12, a_block), where
+// everything a workgroup touches is contiguous.
+struct LevelArgs {
+    const float *value, *ref, *off, *logits;
+    float *out;
+    dfx_msda_level_layout ly;
+    int H, W, Lq, PL, qsplit;
+};
+
+template <int REFDIM>
+__global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
+{
+    const int H = g.H, W = g.W, Lq = g.Lq, PL = g.PL, qsplit = g.qsplit;
+    extern __shared__ float4 img[];                 // [2 planes][PL bordered tokens]
+    const int tid = threadIdx.x;
+    // block -> (frame, head, octet, query slice).  Blocks go round-robin to the 8 XCDs, so the low
+    // 3 bits pick the head: the 4 octets (and the query slices) of one (frame, head) share an L2.
+    const int head = blockIdx.x & 7;
+    const int r = blockIdx.x >> 3;
+    const int per = 4 * qsplit;
+    const int n = r / per, sub = r - n * per;
+    const int oct = sub & 3, qs = sub >> 2;
+    const int S = H * W, WB = W + 2;
+    const int qper = (Lq + qsplit - 1) / qsplit;
+    const int qbeg = qs * qper, qend = min(Lq, qbeg + qper);
+    Level lv;
+    lv.size = (v2f){(float)W, (float)H};
+    lv.rsize = (v2f){1.f / (float)W, 1.f / (float)H};
+    lv.H = H; lv.W = W; lv.WB = WB;
+
+    // ---- issue the staging loads: lane pair = (token, chunk), 32 contiguous bytes per token ----
+    const float *__restrict__ vb = g.value + n * g.ly.value_frame + head * g.ly.value_head + oct * g.ly.value_oct;
+    const long vs_token = g.ly.value_token, vs_chunk = g.ly.value_chunk;
+    float4 v[STAGE_PASSES];
+    const int t0 = tid >> 1, c0 = tid & 1;                  // pass u handles token t0 + u * THREADS / 2
+    {
+        const float *src = vb + t0 * vs_token + c0 * vs_chunk;
+        const long step = (THREADS / 2) * vs_token;
+#pragma unroll
+        for (int u = 0; u < STAGE_PASSES; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
+        }
+    }
+    // ---- parameters of the first query ----
+    const long off_stride = g.ly.off_row, logit_stride = g.ly.logit_row;
+    const float *__restrict__ refn = g.ref + (long)n * Lq * REFDIM;
+    const float *__restrict__ offn = g.off + (long)n * Lq * off_stride + head * g.ly.off_head;
+    const float *__restrict__ lgn = g.logits + (long)n * Lq * logit_stride + head * g.ly.logit_head;
+    float *__restrict__ outn = g.out + (long)n * Lq * g.ly.out_row + head * g.ly.out_head + oct * g.ly.out_oct;
+    const long out_row = g.ly.out_row, out_chunk = g.ly.out_chunk;
+    int q = qbeg + tid;
+    bool have = q < qend;
+    Raw raw;
+    if (have) raw = load_raw<REFDIM>(refn + (long)q * REFDIM, offn + q * off_stride, lgn + q * logit_stride);
+    // ---- zero border: rows 0, H+1, H+2 and columns 0, W+1 of rows 1..H, both planes ----
+    {
+        const int nb = 3 * WB + 2 * H + 1;          // + the token after the last row: (y1, x1) of a sample at (H, W)
+        for (int j = tid; j < 2 * nb; j += THREADS) {
+            const int c = j >= nb, k = j - c * nb;
+            int tb;
+            if (k < WB) tb = k;
+            else if (k <= 3 * WB) tb = (H + 1) * WB + (k - WB);
+            else if (k <= 3 * WB + H) tb = (k - 3 * WB) * WB;
+            else tb = (k - 3 * WB - H) * WB + W + 1;
+            img[c * PL + tb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- taps of the first query while the value loads fly ----
+    Taps tp;
+    if (have) tp = make_taps<REFDIM>(raw, lv);
+    // ---- land the level in LDS: (y, x) of the pass's token advance by a constant step, no division ----
+    {
+        const int dy = (THREADS / 2) / W, dx = (THREADS / 2) - dy * W;
+        int y = t0 / W, x = t0 - y * W;
+        int idx = c0 * PL + (y + 1) * WB + x + 1;
+#pragma unroll
+        for (int u = 0; u < STAGE_PASSES; ++u) {
+            if (t0 + u * (THREADS / 2) < S) img[idx] = v[u];
+            x += dx;
+            idx += dy * WB + dx;
+            if (x >= W) { x -= W; idx += 2; }
+        }
+    }
+    __syncthreads();
+
+    // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters load meanwhile ----
+    while (have) {
+        const int qn = q + THREADS;
+        const bool hn = qn < qend;
+        if (hn) raw = load_raw<REFDIM>(refn + (long)qn * REFDIM, offn + qn * off_stride, lgn + qn * logit_stride);
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float4 *b0 = img + tp.tb[p];
+            const float4 *b1 = b0 + PL;
+            fma4(a0, tp.wt[p].x, b0[0]);
+            fma4(a1, tp.wt[p].x, b1[0]);
+            fma4(a0, tp.wt[p].y, b0[1]);
+            fma4(a1, tp.wt[p].y, b1[1]);
+            fma4(a0, tp.wb[p].x, b0[WB]);
+            fma4(a1, tp.wb[p].x, b1[WB]);
+            fma4(a0, tp.wb[p].y, b0[WB + 1]);
+            fma4(a1, tp.wb[p].y, b1[WB + 1]);
+        }
+        float *dst = outn + q * out_row;
+        *reinterpret_cast<float4 *>(dst) = a0;
+        *reinterpret_cast<float4 *>(dst + out_chunk) = a1;
+        if (hn) tp = make_taps<REFDIM>(raw, lv);
+        q = qn;
+        have = hn;
+    }
+}
+
+// plane stride in tokens: bordered tokens rounded up to 4 mod 8
+inline long plane_tokens(int H, int W)
+{
+    const long nt = (long)(H + 3) * (W + 2);        // one token of border, one more row for y1 of dropped samples
+    return nt + 1 + ((4 - (nt + 1) % 8) + 8) % 8;
+}
+
+}  // namespace
+
+extern "C" int dfx_msda_fused_level_fits(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return 2 * plane_tokens(H, W) * 16 <= LDS_CAP && (long)H * W * 2 <= (long)STAGE_PASSES * THREADS;
+}
+
+extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float *ref, int ref_dim, const float *off,
+                                                const float *logits, const dfx_msda_level_layout *layout, int N,
+                                                int H, int W, int Lq, float *out, void *stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Lq < 0) return dfx::fail(DFX_EINVAL, "msda level: bad dimension");
+    if (N == 0 || Lq == 0) return DFX_OK;
+    if (!value || !ref || !off || !logits || !out || !layout) return dfx::fail(DFX_EINVAL, "msda level: null pointer");
+    if (ref_dim != 2 && ref_dim != 4) return dfx::fail(DFX_EINVAL, "msda level: ref_dim must be 2 or 4");
+    const dfx_msda_level_layout &ly = *layout;
+    const long all = ly.value_frame | ly.value_token | ly.value_head | ly.value_oct | ly.value_chunk | ly.off_row |
+                     ly.off_head | ly.logit_row | ly.logit_head | ly.out_row | ly.out_head | ly.out_oct | ly.out_chunk;
+    if ((all & 3) || all < 0 || ly.value_token < 4 || ly.value_chunk < 4 || ly.off_row < 8 || ly.logit_row < 4 ||
+        ly.out_row < 4 || ly.out_chunk < 4)
+        return dfx::fail(DFX_EINVAL, "msda level: strides must be positive multiples of 4 floats (16-byte vectors)");
+    if (!dfx::aligned16(value) || !dfx::aligned16(out) || !dfx::aligned16(off) || !dfx::aligned16(logits) ||
+        (ref_dim == 4 ? !dfx::aligned16(ref) : ((uintptr_t)ref & 7) != 0))
+        return dfx::fail(DFX_EINVAL, "msda level: buffers must be 16-byte aligned");
+    if (!dfx_msda_fused_level_fits(H, W))
+        return dfx::fail(DFX_EINVAL, "msda level: a %d x %d level does not fit the 160 KB LDS image; "
+                                     "use dfx_msda_fused_forward_f32", H, W);
+    if ((long)N * Lq >= (1L << 28)) return dfx::fail(DFX_ERANGE, "msda level: too many queries");
+    // enough workgroups for the 256 CUs: split the queries of a frame when there are few frames
+    int qsplit = 1;
+    while ((long)N * 32 * qsplit < 256 && qsplit < 8 && Lq / (qsplit * 2) >= THREADS / 2) qsplit *= 2;
+    const long blocks = (long)N * 32 * qsplit;
+    if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "msda level: grid too large");
+    const int PL = (int)plane_tokens(H, W);
+    const size_t lds = (size_t)2 * PL * 16;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool raised = false;                     // LDS images above 64 KB need the per-function opt-in
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_level<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_level<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess)
+            return dfx::fail(DFX_ELAUNCH, "msda level: cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    const int S = H * W;
+    const LevelArgs g{value, ref, off, logits, out, ly, H, W, Lq, PL, qsplit};
+    // algorithmic bytes of this launch: value + (offsets, logits) + out, fp32
+    const long bytes = 4L * ((long)N * S * 256 + 3L * N * Lq * 8 * 4 + (long)N * Lq * 256);
+    if (ref_dim == 2)
+        dfx::launch_timed(bytes, Lq, S, msda_fused_level<2>, dim3((unsigned)blocks), dim3(THREADS), lds, st, g);
+    else
+        dfx::launch_timed(bytes, Lq, S, msda_fused_level<4>, dim3((unsigned)blocks), dim3(THREADS), lds, st, g);
+    return dfx::check_launch("msda_fused_level");
+}

@@ -19,18 +19,28 @@ SIGNATURES = {
     "dfx_profile_enable": [_i],
     "dfx_profile_drain": [_p, _p, _p, _p, _i],
     "dfx_msda_fused_tile_forward_f32": [_p, _p, _i, _p, _l, _p, _l, _i, _i, _i, _p, _p],
+    "dfx_msda_fused_level_fits": [_i, _i],
+    "dfx_msda_fused_level_forward_f32": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     # include/dfx_roi.h: input, rois, N, C, H, W, K, ph, pw, scale, sampling_ratio, aligned, out, stream
     "dfx_roi_align_nchw_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
     "dfx_roi_align_nhwc_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
     # include/dfx_preprocess.h
     "dfx_preprocess_u8_f32": [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _p, _p],
     # include/dfx_gemm.h
-    "dfx_gemm_f32": [_p, _p, _l, _l, _p, _l, _l, _i, _p, _i, _p, _l, _l, _p, _l, _p, _l, _l, _i, _i, _i, _i, _i, _p],
+    "dfx_gemm_f32": [_p, _p, _l, _l, _p, _l, _l, _i, _p, _i, _p, _l, _l, _p, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     # include/dfx_fused.h: x, bias, residual, out, N, C, HW, relu, stream
     "dfx_bias_act_nchw_f32": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
     "dfx_bias_relu_maxpool_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "dfx_add_layernorm_f32": [_p, _p, _p, _p, _p, _l, _i, ctypes.c_float, _p],
 }
+
+
+class LevelLayout(ctypes.Structure):
+    """dfx_msda_level_layout (include/dfx_msda.h): operand strides of the level-in-LDS kernel, in floats."""
+    _fields_ = [(n, ctypes.c_long) for n in (
+        "value_frame", "value_token", "value_head", "value_oct", "value_chunk",
+        "off_row", "off_head", "logit_row", "logit_head",
+        "out_row", "out_head", "out_oct", "out_chunk")]
 
 
 def library_path():

@@ -18,6 +18,12 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 # samples stay inside the staged halo and loses otherwise, so it is opt-in.
 USE_TILE_KERNEL = os.environ.get("DFX_MSDA_TILE", "0") == "1"
 
+# Single-level attention with many queries (encoder, depth fusion) runs on the level-in-LDS kernel
+# (csrc/msda_level.hip) when the level fits the CU's LDS; DFX_MSDA_LEVEL=0 keeps the wave-per-query
+# kernel (A/B measurements).  LEVEL_MIN_QUERIES: below it staging the level costs more than it saves.
+USE_LEVEL_KERNEL = os.environ.get("DFX_MSDA_LEVEL", "1") == "1"
+LEVEL_MIN_QUERIES = 1024
+
 # Measurement hook (bench.py): profile_start() makes every fused MSDA kernel stamp its own begin / end
 # timestamps (include/dfx_msda.h, dfx_profile_*); profile_stop() returns [(seconds, algorithmic_bytes,
 # Lq, S), ...] for the launches in between.
@@ -148,8 +154,17 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     base = qproj.data_ptr()
     host = getattr(spatial_shapes, "_dfx_host", None)
     tile = USE_TILE_KERNEL and host is not None and L == 1 and Lr == 1 and Lq == S == host[0][0] * host[0][1]
+    level = (USE_LEVEL_KERNEL and not tile and host is not None and L == 1 and Lr == 1 and M == 8 and D == 32
+             and P == 4 and S == host[0][0] * host[0][1] and Lq >= LEVEL_MIN_QUERIES
+             and lib.dfx_msda_fused_level_fits(host[0][0], host[0][1]))
     with torch.cuda.device(value.device):
-        if tile:   # encoder / depth-fusion geometry: queries are the pixels of the (single) value map
+        if level:  # the whole level lives in LDS
+            import ctypes
+            ly = _lib.LevelLayout(S * 256, 256, 32, 8, 4, 3 * mlp, 8, 3 * mlp, 4, 256, 32, 8, 4)   # reference layouts
+            rc = lib.dfx_msda_fused_level_forward_f32(
+                value.data_ptr(), reference_points.data_ptr(), ref_dim, base, base + 2 * mlp * 4, ctypes.byref(ly),
+                N, host[0][0], host[0][1], Lq, out.data_ptr(), _stream(value.device))
+        elif tile:   # encoder / depth-fusion geometry: queries are the pixels of the (single) value map
             rc = lib.dfx_msda_fused_tile_forward_f32(
                 value.data_ptr(), reference_points.data_ptr(), ref_dim, base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
                 N, host[0][0], host[0][1], out.data_ptr(), _stream(value.device))
@@ -160,6 +175,46 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
                 base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
                 N, S, M, D, L, Lq, P, out.data_ptr(), _stream(value.device))
     _lib.check(rc, "msda_fused_forward")
+    return out
+
+
+def level_supported(value_like, H, W, Lq, n_heads, head_dim, n_levels, n_points, n_ref_levels):
+    """Single-level attention the level-in-LDS kernel (csrc/msda_level.hip) should run: its
+    geometry, a level that fits the CU's LDS, and enough queries to pay for staging the level."""
+    return (USE_LEVEL_KERNEL and value_like.is_cuda and value_like.dtype == torch.float32 and n_heads == 8
+            and head_dim == 32 and n_points == 4 and n_levels == 1 and n_ref_levels == 1
+            and Lq >= LEVEL_MIN_QUERIES and bool(_lib.load().dfx_msda_fused_level_fits(int(H), int(W))))
+
+
+def msda_level_forward(value_blk, reference_points, qproj_blk, N, H, W):
+    """Fused single-level MSDA on operands in the block-major layouts linear(col_block=...) writes and
+    linear(x_blocked=True) reads (include/dfx_msda.h, dfx_msda_fused_level_forward_f32):
+
+    value_blk        [64, N*H*W, 4]  4-channel chunk k of every token (value_proj, col_block=4)
+    reference_points [N, Lq, 1, 2|4]
+    qproj_blk        [8, N*Lq, 12]   per head: 4 points x (x, y) offsets, then the 4 logits (col_block=12 of the
+                                     head-interleaved sampling_offsets / attention_weights Linear)
+    -> [64, N*Lq, 4]  the sampled values, 4-channel chunk k of every query (output_proj's x_blocked operand)
+    """
+    import ctypes
+    lib = _lib.load()
+    reference_points = reference_points.contiguous()
+    _check_inputs([("value_blk", value_blk), ("reference_points", reference_points), ("qproj_blk", qproj_blk)])
+    S = H * W
+    Lq, ref_dim = reference_points.shape[1], reference_points.shape[3]
+    _require(value_blk.shape == (64, N * S, 4) and value_blk.dtype == torch.float32, "value_blk must be [64, N*H*W, 4] fp32")
+    _require(qproj_blk.shape == (8, N * Lq, 12) and qproj_blk.dtype == torch.float32, "qproj_blk must be [8, N*Lq, 12] fp32")
+    _require(reference_points.shape[0] == N and reference_points.shape[2] == 1 and reference_points.dtype == torch.float32,
+             "reference_points must be [N, Lq, 1, 2|4] fp32")
+    out = torch.empty((64, N * Lq, 4), dtype=torch.float32, device=value_blk.device)
+    base = qproj_blk.data_ptr()
+    ns, nq = N * S, N * Lq
+    ly = _lib.LevelLayout(S * 4, 4, 32 * ns, 8 * ns, 4 * ns, 12, 12 * nq, 12, 12 * nq, 4, 32 * nq, 8 * nq, 4 * nq)
+    with torch.cuda.device(value_blk.device):
+        rc = lib.dfx_msda_fused_level_forward_f32(
+            value_blk.data_ptr(), reference_points.data_ptr(), ref_dim, base, base + 32, ctypes.byref(ly),
+            N, H, W, Lq, out.data_ptr(), _stream(value_blk.device))
+    _lib.check(rc, "msda_level_forward")
     return out
 
 
@@ -216,16 +271,24 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None):
+def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False):
     """y = act((x (+ add)) @ weight.T + bias (+ residual)), rows where row_mask is True set to 0.
     The hand-written fp32 MFMA GEMM (include/dfx_gemm.h) standing in for nn.Linear with its
     neighbours fused: the ``src + pos`` query add, the bias, ReLU, the residual add and
-    value_proj's masked_fill.  x [..., K] contiguous, weight [N, K] -> [..., N]."""
+    value_proj's masked_fill.  x [..., K] contiguous, weight [N, K] -> [..., N].
+
+    col_block = w > 0 stores the result column-block-major instead: [N / w, rows, w] (the layout
+    msda_level_forward reads), N a multiple of w.  x_blocked: x is K-block-major [K/4, rows, 4] (the
+    layout msda_level_forward writes); the result is then [rows, N]."""
     lib = _lib.load()
-    K = x.shape[-1]
     N = weight.shape[0]
-    x2 = x.reshape(-1, K)
-    M = x2.shape[0]
+    if x_blocked:
+        _require(x.dim() == 3 and x.shape[2] == 4 and add is None, "x_blocked: x must be [K/4, rows, 4], no add")
+        K, M, x2 = x.shape[0] * 4, x.shape[1], x
+    else:
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
     named = [("x", x2), ("weight", weight)]
     for nm, t in (("bias", bias), ("residual", residual), ("add", add), ("row_mask", row_mask)):
         if t is not None:
@@ -235,16 +298,24 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
     _require(weight.shape[1] == K and K % 4 == 0, "weight must be [N, K] with K a multiple of 4")
     if add is not None:
         _require(add.shape == x.shape, "add must match x")
-    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if col_block:
+        _require(N % col_block == 0 and residual is None, "col_block must divide N; no residual in this layout")
+        out = torch.empty((N // col_block, M, col_block), dtype=x.dtype, device=x.device)
+    elif x_blocked:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    else:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
     if residual is not None:
-        _require(residual.shape == out.shape, "residual must match the output")
+        _require(residual.shape == out.shape or (x_blocked and residual.numel() == out.numel()),
+                 "residual must match the output")
     if row_mask is not None:
         _require(row_mask.numel() == M, "row_mask must have one entry per row")
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
     with torch.cuda.device(x.device):
         rc = lib.dfx_gemm_f32(x2.data_ptr(), _ptr(add), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), 0,
                               _ptr(residual), N, 0, _ptr(row_mask), 0, out.data_ptr(), N, 0, M, N, K, 1,
-                              int(bool(relu)), _stream(x.device))
+                              int(bool(relu)), int(col_block), M * int(col_block), M * 4 if x_blocked else 0,
+                              _stream(x.device))
     _lib.check(rc, "linear")
     return out
 
@@ -269,7 +340,7 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     with torch.cuda.device(x.device):
         rc = lib.dfx_gemm_f32(w2.data_ptr(), 0, Ci, 0, x.data_ptr(), HW, Ci * HW, 1, _ptr(bias), 1,
                               _ptr(residual), HW, Co * HW, 0, 0, out.data_ptr(), HW, Co * HW, Co, HW, Ci, Nb,
-                              int(bool(relu)), _stream(x.device))
+                              int(bool(relu)), 0, 0, 0, _stream(x.device))
     _lib.check(rc, "conv1x1")
     return out
 

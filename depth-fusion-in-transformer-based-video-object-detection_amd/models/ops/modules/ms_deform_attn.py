@@ -77,6 +77,20 @@ class MSDeformAttn(nn.Module):
             self._qproj_cache = (key, w, b)
         return self._qproj_cache[1], self._qproj_cache[2]
 
+    def _qproj_params_by_head(self):
+        """The joint projection with its output columns regrouped per head - [8 offsets | 4 logits] x n_heads
+        (n_levels == 1) - so that a col_block=12 GEMM writes what one workgroup of the level-in-LDS kernel
+        reads as one contiguous slab."""
+        w, b = self._qproj_params()
+        if self._qproj_cache[0] != getattr(self, "_qproj_head_key", None):
+            M, P = self.n_heads, self.n_points
+            so = torch.arange(M * P * 2, device=w.device).view(M, P * 2)
+            aw = torch.arange(M * P, device=w.device).view(M, P) + M * P * 2
+            order = torch.cat([so, aw], 1).reshape(-1)
+            self._qproj_head = (w[order].contiguous(), b[order].contiguous())
+            self._qproj_head_key = self._qproj_cache[0]
+        return self._qproj_head
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query [N,Lq,C] (or a (tensor, positional_embedding) pair whose sum is the query: the add is
@@ -98,6 +112,18 @@ class MSDeformAttn(nn.Module):
         no_grad = not torch.is_grad_enabled() or not (query.requires_grad or input_flatten.requires_grad)
         fused = no_grad and input_flatten.is_cuda and input_flatten.dtype == torch.float32 \
             and _ops.fused_supported(input_flatten, M, D, L, P, reference_points.shape[2])
+        host = getattr(input_spatial_shapes, "_dfx_host", None)
+        if fused and host is not None and _ops.level_supported(input_flatten, host[0][0], host[0][1], Lq, M, D, L, P,
+                                                               reference_points.shape[2]):
+            # single-level attention over many queries (encoder, depth fusion): the level lives in LDS and
+            # the three projections exchange block-major operands with the kernel (include/dfx_msda.h)
+            q, q_add = query if isinstance(query, tuple) else (query, None)
+            w, b = self._qproj_params_by_head()
+            value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
+                                row_mask=input_padding_mask, col_block=4)
+            qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous(), col_block=12)
+            sampled = _ops.msda_level_forward(value, reference_points, qproj, N, host[0][0], host[0][1])
+            return _ops.linear(sampled, self.output_proj.weight, self.output_proj.bias, x_blocked=True).view(N, Lq, -1)
         if fused:
             # value_proj (+ masked_fill of padded tokens), [offsets | logits] in one GEMM (+ the
             # caller's ``src + pos`` add when handed over as a (src, pos) pair), fused sampling

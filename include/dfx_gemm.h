@@ -14,13 +14,19 @@
  *   C[b] = act( (A[b] (+ A2[b])) x op(B[b]) + bias (+ R[b]) ), rows with row_mask != 0 forced to 0
  *
  *   A   [M,K] row-major, leading dimension lda; batch stride strideA (0 = shared by all batches)
+ *       or, with a_block_stride > 0, K-block-major [K/4][M][4]: element (m, k) at
+ *       A[(k / 4) * a_block_stride + m * 4 + k % 4] (the layout the level-in-LDS MSDA kernel writes its
+ *       output in, consumed by output_proj; lda is ignored, no A2)
  *   A2  optional, same layout as A, added element-wise while A is staged (query = src + pos)
  *   B   b_is_kn = 1: [K,N] row-major (ldb >= N)  -- activations of a 1x1 convolution, NCHW
  *       b_is_kn = 0: [N,K] row-major (ldb >= K)  -- an nn.Linear weight
  *   bias optional; bias_per_row = 1: bias[m] (convolution), 0: bias[n] (Linear)
  *   R   optional residual, layout of C (ldr, strideR)
  *   row_mask optional uint8[M] per batch (strideMask): value_proj's masked_fill of padded tokens
- *   C   [M,N] row-major, ldc
+ *   C   [M,N] row-major, ldc; or, with c_block = w > 0, column-block-major: element (m, n) at
+ *       C[(n / w) * c_block_stride + m * w + n % w] - the layout the level-in-LDS MSDA kernel
+ *       (dfx_msda.h) reads: value_proj output as [32 channel octets][tokens][8], the joint
+ *       sampling_offsets / attention_weights output as [8 heads][queries][12] (no residual then)
  * fp32 in, fp32 accumulate (exact fp32 MFMA), fp32 out.  K must be a multiple of 4; A, B rows
  * 16-byte aligned.  Same conventions as dfx_msda.h (device pointers, enqueue-only, 0 / <0).
  */
@@ -37,7 +43,8 @@ int dfx_gemm_f32(const float *A, const float *A2, long lda, long strideA,
                  const float *R, long ldr, long strideR,
                  const unsigned char *row_mask, long strideMask,
                  float *C, long ldc, long strideC,
-                 int M, int N, int K, int batch, int relu, void *stream);
+                 int M, int N, int K, int batch, int relu,
+                 int c_block, long c_block_stride, long a_block_stride, void *stream);
 
 #ifdef __cplusplus
 }

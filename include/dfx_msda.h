@@ -129,6 +129,47 @@ int dfx_msda_fused_tile_forward_f32(const float *value, const float *ref, int re
                                     const float *logits, long logit_stride,
                                     int N, int H, int W, float *out, void *stream);
 
+/*
+ * The same fused operator for single-level attention with the whole level resident in LDS
+ * (csrc/msda_level.hip): L = 1, one reference level, P = 4, M = 8, D = 32, any Lq.  A workgroup
+ * stages 8 channels of one head of every token of the H x W map (zero-bordered) into LDS and the
+ * bilinear gathers never leave the CU.  H and W are HOST integers (the LDS image is sized from
+ * them); the level must fit: dfx_msda_fused_level_fits(H, W) != 0, i.e. (H+3)*(W+2)*32 B within
+ * the CU's 160 KB (50 x 84 at 800 x 1333 does).  Results equal dfx_msda_fused_forward_f32 up to
+ * rounding (softmax and the location quotient are computed with correctly rounded divisions, the
+ * exponential to 1 ulp).  Replaces the same reference lines as dfx_msda_fused_forward_f32
+ * (models/ops/modules/ms_deform_attn.py:98-114).
+ *
+ * Operands are addressed through dfx_msda_level_layout (strides in floats, multiples of 4):
+ *   value   channel c of head m of token s of frame n at
+ *           value[n*value_frame + s*value_token + m*value_head + (c/8)*value_oct + ((c/4)%2)*value_chunk + c%4]
+ *           reference layout [N,S,8,32]: (S*256, 256, 32, 8, 4); the layout the kernel is built for is
+ *           dfx_gemm_f32's c_block = 4 output [64][N*S][4]: (S*4, 4, 32*N*S, 8*N*S, 4*N*S), where every
+ *           16-byte chunk plane a workgroup stages is contiguous
+ *   off     the 4 (x, y) offsets of head m of query row r = n*Lq + q at off[r*off_row + m*off_head + 0..7]
+ *   logits  its 4 attention logits at logits[r*logit_row + m*logit_head + 0..3]
+ *           reference Linear outputs: off (64-float rows, head stride 8), logits (32-float rows, head
+ *           stride 4); built-for layout: one c_block = 12 GEMM output [8][N*Lq][12] holding
+ *           (offsets, logits) of a head side by side: off_row = logit_row = 12,
+ *           off_head = logit_head = N*Lq*12, logits = off + 8
+ *   out     channel c of head m of query row r at
+ *           out[r*out_row + m*out_head + (c/8)*out_oct + ((c/4)%2)*out_chunk + c%4]
+ *           reference layout [N,Lq,256]: (256, 32, 8, 4); built-for layout [64][N*Lq][4]
+ *           (dfx_gemm_f32's K-block-major A operand of output_proj): (4, 32*N*Lq, 8*N*Lq, 4*N*Lq)
+ *   ref [N,Lq,1,ref_dim]
+ */
+typedef struct dfx_msda_level_layout {
+    long value_frame, value_token, value_head, value_oct, value_chunk;
+    long off_row, off_head, logit_row, logit_head;
+    long out_row, out_head, out_oct, out_chunk;
+} dfx_msda_level_layout;
+
+int dfx_msda_fused_level_fits(int H, int W);
+int dfx_msda_fused_level_forward_f32(const float *value, const float *ref, int ref_dim,
+                                     const float *off, const float *logits,
+                                     const dfx_msda_level_layout *layout,
+                                     int N, int H, int W, int Lq, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,27 @@ def test_linear_matches_fp64(M, N, K, variant):
     assert (got.double() - want).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K,w", [(4200, 256, 256, 4), (8400, 96, 256, 12), (333, 96, 64, 12), (130, 256, 260, 8),
+                                     (5, 12, 8, 4)])
+def test_linear_block_major_layouts(M, N, K, w):
+    """col_block stores C as [N/w][M][w]; x_blocked reads A as [K/4][M][4] - the layouts between the
+    projections and the level-in-LDS MSDA kernel.  Same arithmetic as the row-major call: equal bits."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(M * 7 + N + K + w)
+    x = torch.randn(M, K, generator=g).cuda()
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    mask = (torch.rand(M, generator=g) > 0.8).cuda()
+    plain = ops.linear(x, wt, b, row_mask=mask)
+    blk = ops.linear(x, wt, b, row_mask=mask, col_block=w)
+    assert blk.shape == (N // w, M, w)
+    assert torch.equal(blk.permute(1, 0, 2).reshape(M, N), plain)
+    xb = x.view(M, K // 4, 4).permute(1, 0, 2).contiguous()
+    res = torch.randn(M, N, generator=g).cuda()
+    assert torch.equal(ops.linear(xb, wt, b, relu=True, residual=res, x_blocked=True),
+                       ops.linear(x, wt, b, relu=True, residual=res))
+
+
 @pytest.mark.parametrize("Nb,Ci,Co,H,W", [(2, 64, 256, 20, 34), (3, 256, 64, 10, 18), (1, 1024, 512, 8, 12),
                                           (2, 2048, 256, 5, 8), (2, 128, 256, 50, 84)])
 def test_conv1x1_matches_torch(Nb, Ci, Co, H, W):

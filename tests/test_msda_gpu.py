@@ -304,3 +304,122 @@ def test_tile_kernel_matches_oracle(msda, oracle, H, W, N, ref_dim, spread):
         ops.USE_TILE_KERNEL = saved
     assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
     assert torch.allclose(got, plain, rtol=1e-5, atol=1e-5)
+
+
+# ---- level-in-LDS kernel for single-level attention (csrc/msda_level.hip) ------------------------
+def _level_case(seed, H, W, N, Lq, ref_dim, spread, raster):
+    g = torch.Generator().manual_seed(seed)
+    M, P, S = 8, 4, H * W
+    value = torch.randn(N, S, M, 32, generator=g)
+    qproj = torch.randn(N, Lq, 3 * M * P, generator=g)
+    qproj[..., : 2 * M * P] *= spread
+    if raster:      # encoder: the queries are the pixels of the map
+        ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
+        xy = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).view(1, S, 1, 2).expand(N, S, 1, 2)
+    else:
+        xy = torch.rand(N, Lq, 1, 2, generator=g) * 1.2 - 0.1
+    ref = xy.contiguous() if ref_dim == 2 else torch.cat([xy, torch.rand(N, Lq, 1, 2, generator=g) * 0.5], -1).contiguous()
+    return value, qproj, ref
+
+
+def _level_expect(oracle, value, qproj, ref, H, W):
+    N, Lq = qproj.shape[:2]
+    M, P = 8, 4
+    off = qproj[..., : 2 * M * P].reshape(N, Lq, M, 1, P, 2)
+    if ref.shape[-1] == 2:
+        loc = ref[:, :, None, :, None, :] + off / torch.tensor([W, H], dtype=torch.float32)
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    aw = torch.softmax(qproj[..., 2 * M * P:].reshape(N, Lq, M, P), -1).view(N, Lq, M, 1, P)
+    shapes = torch.as_tensor([(H, W)], dtype=torch.long)
+    return oracle.msda_forward(value, shapes, lsi_of(shapes), loc.contiguous(), aw)
+
+
+def _run_level(value, qproj, ref, H, W, level):
+    from dfx import ops
+    from models.transformer_layers import make_level_tensors
+    shapes, lsi = make_level_tensors([(H, W)], "cuda")
+    saved = ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES
+    try:
+        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES = level, 0
+        return ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, 4)
+    finally:
+        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES = saved
+
+
+def _run_level_blocked(value, qproj, ref, H, W):
+    """Operands re-laid out as dfx_gemm_f32's block-major outputs; the result back in [N,Lq,256]."""
+    from dfx import ops
+    N, S = value.shape[:2]
+    Lq = qproj.shape[1]
+    vb = value.view(N, S, 64, 4).permute(2, 0, 1, 3).reshape(64, N * S, 4).contiguous().cuda()
+    qb = torch.cat([qproj[..., :64].view(N, Lq, 8, 8), qproj[..., 64:].view(N, Lq, 8, 4)], -1) \
+        .permute(2, 0, 1, 3).reshape(8, N * Lq, 12).contiguous().cuda()
+    out = ops.msda_level_forward(vb, ref.cuda(), qb, N, H, W)
+    return out.view(64, N, Lq, 4).permute(1, 2, 0, 3).reshape(N, Lq, 256)
+
+
+@pytest.mark.parametrize("H,W,N,Lq,ref_dim,spread,raster", [
+    (50, 84, 2, 4200, 2, 3.0, True),      # production map, offsets of a few pixels
+    (50, 84, 8, 4200, 2, 1.0, True),      # the bench launch: 256 workgroups, one per CU
+    (50, 84, 1, 4200, 2, 30.0, True),     # large offsets, N = 1: queries split over 8 workgroups per octet
+    (50, 84, 3, 300, 4, 8.0, False),      # decoder-like: few queries, box references
+    (50, 84, 1, 5000, 2, 5.0, False),     # Lq != S, random references incl. outside [0,1]
+    (13, 21, 3, 273, 2, 4.0, True), (7, 9, 2, 100, 4, 2.0, False), (1, 1, 2, 5, 2, 1.0, False),
+    (33, 5, 1, 1111, 2, 6.0, False), (55, 86, 1, 2000, 2, 4.0, False),     # 55 x 86: about the largest map that fits
+])
+def test_level_kernel_matches_oracle(msda, oracle, H, W, N, Lq, ref_dim, spread, raster):
+    from dfx import _lib
+    assert _lib.load().dfx_msda_fused_level_fits(H, W) == 1
+    value, qproj, ref = _level_case(H * 131 + W + N, H, W, N, Lq, ref_dim, spread, raster)
+    expect = _level_expect(oracle, value, qproj, ref, H, W)
+    got = _run_level(value, qproj, ref, H, W, True)
+    plain = _run_level(value, qproj, ref, H, W, False)     # the wave-per-query kernel on the same inputs
+    assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
+    assert torch.allclose(got, plain, rtol=1e-5, atol=1e-5)
+    # the block-major operand layouts the model path uses: same kernel, same arithmetic -> same bits
+    assert torch.equal(_run_level_blocked(value, qproj, ref, H, W), got)
+
+
+def test_level_kernel_edges(msda, oracle):
+    """Samples exactly on the skip-rule bounds (h_im = -1, H-1, H; w_im likewise), NaN / inf offsets and
+    -inf logits: the same answer as the oracle (a dropped sample contributes 0)."""
+    H, W, N, Lq = 6, 10, 1, 64
+    value, qproj, ref = _level_case(5, H, W, N, Lq, 2, 1.0, False)
+    off = qproj[..., :64].view(N, Lq, 8, 4, 2)
+    # location = ref + off / (W, H); pick ref = 0 and offsets that give pixel coordinates k - 0.5 exactly
+    ref.zero_()
+    ks = torch.tensor([-0.5, 0.0, 0.5, H - 0.5, H, H + 0.5, W - 0.5, W, W + 0.5, 1.0, 2.5, -3.0])
+    for q in range(Lq):
+        for m in range(8):
+            for p in range(4):
+                off[0, q, m, p, 0] = ks[(q + m + p) % len(ks)]           # x offset in pixels (divided by W)
+                off[0, q, m, p, 1] = ks[(q * 3 + m * 5 + p * 7) % len(ks)]
+    off[0, 3, 1, 2, 0] = float("nan")
+    off[0, 4, 2, 1, 1] = float("inf")
+    off[0, 5, 3, 0, 0] = float("-inf")
+    qproj[0, 6, 64 + 4 * 2 + 1] = float("-inf")        # one masked logit of (query 6, head 2)
+    expect = _level_expect(oracle, value, qproj, ref, H, W)
+    got = _run_level(value, qproj, ref, H, W, True)
+    assert torch.isfinite(expect).all() and torch.isfinite(got).all()
+    assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
+
+
+def test_level_kernel_refuses_large_maps(msda):
+    from dfx import _lib
+    lib = _lib.load()
+    assert lib.dfx_msda_fused_level_fits(100, 167) == 0
+    assert lib.dfx_msda_fused_level_fits(0, 5) == 0
+    import ctypes
+    v = torch.zeros(1, 100 * 167, 8, 32, device="cuda")
+    q = torch.zeros(1, 10, 96, device="cuda")
+    r = torch.zeros(1, 10, 1, 2, device="cuda")
+    o = torch.zeros(1, 10, 256, device="cuda")
+    ly = _lib.LevelLayout(100 * 167 * 256, 256, 32, 8, 4, 96, 8, 96, 4, 256, 32, 8, 4)
+    rc = lib.dfx_msda_fused_level_forward_f32(v.data_ptr(), r.data_ptr(), 2, q.data_ptr(), q.data_ptr() + 256,
+                                              ctypes.byref(ly), 1, 100, 167, 10, o.data_ptr(), None)
+    assert rc < 0 and b"does not fit" in lib.dfx_last_error()
+    ly.off_row = 6                                       # not a multiple of 4 floats
+    rc = lib.dfx_msda_fused_level_forward_f32(v.data_ptr(), r.data_ptr(), 2, q.data_ptr(), q.data_ptr() + 256,
+                                              ctypes.byref(ly), 1, 10, 10, 10, o.data_ptr(), None)
+    assert rc < 0 and b"strides" in lib.dfx_last_error()

@@ -73,10 +73,11 @@ def main():
             for spread in (1.0, 3.0):
                 q2 = qproj.clone()
                 q2[..., : 2 * M * L * P] *= spread
-                for flag in (False, True):
-                    ops.USE_TILE_KERNEL = flag
+                for mode in ("wave", "level", "tile"):
+                    ops.USE_TILE_KERNEL, ops.USE_LEVEL_KERNEL = mode == "tile", mode == "level"
                     tt = timeit(lambda: ops.msda_fused_forward(value, sh2, lsi2, grid, q2, L, P), a.iters)
-                    line += f" | sd{spread:.0f}px {'tile' if flag else 'wave'} {tt*1e6:7.1f} us {nbytes/tt/1e9:7.1f} GB/s"
+                    line += f" | sd{spread:.0f}px {mode} {tt*1e6:7.1f} us {nbytes/tt/1e9:7.1f} GB/s"
+                ops.USE_TILE_KERNEL, ops.USE_LEVEL_KERNEL = False, True
         print(line, flush=True)
 
 
