@@ -44,7 +44,7 @@ torch.backends.cudnn.allow_tf32 = False
 # HBM-side traffic of one MSDA encoder-geometry launch, per frame, from the PMC passes committed in
 # profiles/r01_pmc_msda_fused_enc_N8.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 8 frames, the
 # factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
-MSDA_TRAFFIC_PER_FRAME = (2 * 24100.0 + 33600.0) * 1024 / 8
+MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
 
 # per-frame algorithmic work of config E (all-current mode)
 BYTES_PER_FRAME = 4.333e9
@@ -164,7 +164,7 @@ def main():
                     "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
                     "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, per_rank)),
-                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_msda_fused_enc_N8.md",
+                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_msda_level_N8.md",
                     "launches": len(enc), "bytes_per_launch": nbytes, "avg_launch_us": round(mean_t * 1e6, 2)}
         line = {
             "metric": "frames/sec at 800x1333 RGB-D, TransVOD++ Late-Fusion", "value": round(fps, 3),

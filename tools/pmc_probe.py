@@ -43,3 +43,11 @@ nb = 4 * (N * S * M * D + 3 * N * S * M * L * P + N * S * M * D)
 print("msda_fused enc: algorithmic bytes per launch", nb, "(value", 4 * N * S * M * D, "qproj", 12 * N * S * M * L * P,
       "out", 4 * N * S * M * D, ")")
 torch.cuda.synchronize()
+# 3. the level-in-LDS kernel on the same problem, operands in the block-major layouts the model path uses
+value_blk_shape, qb = (64, N * S, 4), torch.cat([qproj[..., :64].view(N, S, 8, 8), qproj[..., 64:].view(N, S, 8, 4)], -1) \
+    .permute(2, 0, 1, 3).reshape(8, N * S, 12).contiguous()
+for _ in range(a.reps):
+    value_blk = torch.randn(value_blk_shape, device=dev)
+    ops.msda_level_forward(value_blk, ref, qb, N, 50, 84)
+print("msda_fused_level: same algorithmic bytes per launch", nb)
+torch.cuda.synchronize()
