@@ -1,0 +1,53 @@
+"""Time ONE rank's share of the 32-frame clip on one GPU, for several (frames per rank, micro-batch,
+overlap) choices: frames_forward on the rank's F frames, the all-gather replaced by a local copy of
+[T,300,259] (its cost on xGMI is ~10 us), temporal_forward against all T frames' queries.
+
+    python tools/rank_step.py [T=32]
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd"))
+sys.path.insert(0, ROOT)
+from bench import build  # noqa: E402
+from models.clip_inference import ClipRunner  # noqa: E402
+
+torch.backends.cuda.matmul.allow_tf32 = False
+torch.backends.cudnn.allow_tf32 = False
+torch.backends.cudnn.deterministic = os.environ.get("DET", "0") == "1"
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda")
+model = build(dev, T - 1)
+clip = torch.randn(T, 4, 800, 1333, generator=torch.Generator().manual_seed(42))
+
+
+def rank_step(runner, x):
+    local = runner.frames_forward(x)
+    F_ = x.shape[0]
+    rep = T // F_
+    all_ref = local["ref"].repeat(rep, 1, 1)            # stands in for the gathered queries of the other ranks
+    all_logits = local["logits"].repeat(rep, 1, 1)
+    return runner.temporal_forward(local, all_ref, all_logits, first_frame=0)
+
+
+for F_, mb, ov in [(32, 8, False), (32, 8, True), (16, 8, False), (16, 8, True), (16, 4, True), (8, 8, False),
+                   (8, 4, True), (8, 2, True), (4, 4, False), (4, 2, True), (4, 1, True)]:
+    if F_ > T:
+        continue
+    x = clip[:F_].to(dev)
+    runner = ClipRunner(model, micro_batch=mb, overlap=ov)
+    for _ in range(2):
+        rank_step(runner, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 4
+    for _ in range(n):
+        rank_step(runner, x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"frames/rank {F_:2d} (N={T // F_} GPUs)  micro-batch {mb}  overlap {int(ov)}: {dt * 1e3:7.2f} ms/step "
+          f"-> {T / dt:7.1f} frames/s whole job", flush=True)
