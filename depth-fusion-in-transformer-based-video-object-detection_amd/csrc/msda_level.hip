@@ -42,7 +42,7 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 
 struct Taps {
-    int tb[4];          // bordered token index of corner (y0, x0) of each point
+    int tb[4];          // y0 * (W+2) + x0 of each point (>= -(W+3)): token index relative to image token (1, 1)
     v2f wt[4], wb[4];   // corner weights {(y0,x0), (y0,x1)} and {(y1,x0), (y1,x1)}, attention weight folded in
 };
 
@@ -68,20 +68,18 @@ __device__ __forceinline__ Raw load_raw(const float *__restrict__ rp, const floa
     return w;
 }
 
-// exp(x) for x <= 0 (logit - max), two at a time: 2^(x*log2e) with the product's low part carried
-// (1 ulp, like libm's expf), without the overflow / denormal branches (x is clamped at -87).
+// exp(x) for x <= 0 (logit - max), two at a time: 2^t * (1 + f ln2) with t = RN(x log2e) and f the
+// rounding error of that product (an fma away) - v_exp_f32's 1 ulp plus ~1e-8 |x|, without libm's
+// range reduction (x is clamped at -87, where the result is 1e-38).
 __device__ __forceinline__ v2f exp_neg(v2f x)
 {
     x.x = fmaxf(x.x, -87.f);
     x.y = fmaxf(x.y, -87.f);
-    const v2f L2E = splat(1.4426950216293335f), L2E_LO = splat(1.9259629911266175e-8f);
+    const v2f L2E = splat(1.4426950216293335f);
     const v2f t = x * L2E;
-    v2f f = pk_fma(x, L2E, -t);
-    f = pk_fma(x, L2E_LO, f);
-    const v2f r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
-    const v2f a = (t - r) + f;
-    return (v2f){__builtin_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)r.x),
-                 __builtin_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)r.y)};
+    const v2f f = pk_fma(x, L2E, -t) * splat(0.6931471805599453f);
+    const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    return pk_fma(e, f, e);
 }
 
 // Per-thread constants of the level.
@@ -128,9 +126,10 @@ __device__ __forceinline__ Taps make_taps(const Raw &in, const Level &lv)
         // clamp to [-1, size]: NaN and -inf land on -1 (zero border, weight 0), +inf on `size` (dropped below)
         const float ws = __builtin_amdgcn_fmed3f(im.x, -1.f, lv.size.x);
         const float hs = __builtin_amdgcn_fmed3f(im.y, -1.f, lv.size.y);
-        const float wf = floorf(ws), hf = floorf(hs);
-        const int ix = (int)wf, iy = (int)hf;
-        const v2f l = (v2f){ws, hs} - (v2f){wf, hf};                     // (lw, lh)
+        int ix, iy;                                                      // floor to int in one instruction
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(ws));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(hs));
+        const v2f l = {__builtin_amdgcn_fractf(ws), __builtin_amdgcn_fractf(hs)};   // (lw, lh) = x - floor(x), exact
         const v2f hc = splat(1.f) - l;                                   // (hw, hh)
         // the skip rule -1 < h_im < H, -1 < w_im < W: a sample at exactly -1 has weight 0 on its only
         // in-map row/column already, so only the upper bounds are left to test
@@ -138,7 +137,8 @@ __device__ __forceinline__ Taps make_taps(const Raw &in, const Level &lv)
         const v2f xw = {hc.x, l.x};                                      // (hw, lw)
         t.wt[p] = splat(hc.y) * xw * splat(aa);
         t.wb[p] = splat(l.y) * xw * splat(aa);
-        t.tb[p] = (iy + 1) * lv.WB + ix + 1;                             // rows 0..H+1 (+1 more for y1)
+        // iy * WB + ix; the (+1, +1) of the border is folded into the image base by the caller (rows 0..H+1)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t.tb[p]) : "v"(iy), "v"(lv.WB), "v"(ix));
     }
     return t;
 }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
         const long step = (THREADS / 2) * vs_token;
 #pragma unroll
         for (int u = 0; u < STAGE_PASSES; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // straight-line, per-lane predicated: all loads in flight at once
             if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
         }
     }
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
     __syncthreads();
 
     // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters load meanwhile ----
+    const float4 *org = img + WB + 1;               // token (y, x) = (0, 0) of the map inside the bordered image
     while (have) {
         const int qn = q + THREADS;
         const bool hn = qn < qend;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const float4 *b0 = img + tp.tb[p];
+            const float4 *b0 = org + tp.tb[p];
             const float4 *b1 = b0 + PL;
             fma4(a0, tp.wt[p].x, b0[0]);
             fma4(a1, tp.wt[p].x, b1[0]);
