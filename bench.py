@@ -102,7 +102,9 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="clip length T (fixed across N)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
-    ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--micro-batch", type=int, default=32,
+                    help="frames per pass through the spatial stage (capped at the frames of the rank); larger "
+                         "is faster up to the whole block: 8 -> 143.3, 16 -> 131.6, 32 -> 127.3 ms per 32-frame clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--overlap", type=int, default=1,

@@ -162,11 +162,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) b[nxt][j] = Bs[buf][kk * 2 + 2 + half][wn * TN + j * 32 + c];
             }
+            // keep the LDS reads of the next k-pair AHEAD of this k-pair's MFMAs (left alone, the scheduler
+            // reuses the fragment registers and sinks the reads below the MFMAs, exposing their latency)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < steps) store_tiles(buf ^ 1);
         __syncthreads();

@@ -1,21 +1,31 @@
-"""A few GEMM launches for PMC passes (rocprofv3 --pmc ...): conv1x1 shapes of ResNet layer4 / layer1."""
+"""A few GEMM launches for PMC passes (rocprofv3 --pmc ...): the hand-written kernel and the library on
+the same shapes (conv1x1 of ResNet layer4 / layer1, the encoder projections and FFN)."""
 import os
 import sys
 
 import torch
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd"))
 from dfx import ops  # noqa: E402
 
-for Ci, Co, H, W in ((1024, 2048, 50, 84), (512, 2048, 50, 84), (64, 256, 200, 334)):
+torch.backends.cuda.matmul.allow_tf32 = False
+torch.backends.cudnn.allow_tf32 = False
+for Ci, Co, H, W in ((1024, 2048, 50, 84), (512, 2048, 50, 84), (64, 256, 200, 334), (2048, 256, 50, 84)):
     x = torch.randn(8, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 1, 1, device="cuda") / Ci ** 0.5
     b = torch.randn(Co, device="cuda")
     for _ in range(3):
         ops.conv1x1(x, w, b, relu=True)
-x = torch.randn(33600, 256, device="cuda")
-w = torch.randn(1024, 256, device="cuda") / 16
-for _ in range(3):
-    ops.linear(x, w, None, relu=True)
+    for _ in range(3):
+        F.conv2d(x, w)
+for M, N, K in ((33600, 256, 256), (33600, 1024, 256), (33600, 256, 1024), (33600, 96, 256)):
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / 16
+    b = torch.randn(N, device="cuda")
+    for _ in range(3):
+        ops.linear(x, w, b)
+    for _ in range(3):
+        F.linear(x, w, b)
 torch.cuda.synchronize()

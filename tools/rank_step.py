@@ -34,7 +34,8 @@ def rank_step(runner, x):
     return runner.temporal_forward(local, all_ref, all_logits, first_frame=0)
 
 
-for F_, mb, ov in [(32, 8, False), (32, 8, True), (16, 8, False), (16, 8, True), (16, 4, True), (8, 8, False),
+CASES = os.environ.get('CASES')
+for F_, mb, ov in eval(CASES) if CASES else [(32, 8, False), (32, 8, True), (16, 8, False), (16, 8, True), (16, 4, True), (8, 8, False),
                    (8, 4, True), (8, 2, True), (4, 4, False), (4, 2, True), (4, 1, True)]:
     if F_ > T:
         continue
