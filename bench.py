@@ -13,11 +13,14 @@ one RCCL all-gather of the per-frame reference query sets per step.  A step = th
 Inputs are resident in HBM before the timed region.  Compute type fp32 throughout.
 
 The JSON line also carries
-  roofline     the MSDA forward kernel at the encoder geometry (N = frames per micro-batch,
-               Lq = S = 4200, L = 1): algorithmic bytes 4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per
-               launch over the mean kernel duration of those launches inside the timed steps, taken
-               from HIP events that the launch itself stamps on its stream (hipExtLaunchKernelGGL);
-               peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
+  roofline     the MSDA forward kernel at the encoder geometry (csrc/msda_level.hip; N = frames per
+               micro-batch = the rank's frames by default, Lq = S = 4200, L = 1): algorithmic bytes
+               4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per launch over the mean kernel duration of those
+               launches inside the timed steps, taken from HIP events that the launch itself stamps on
+               its stream (hipExtLaunchKernelGGL); peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  With the
+               two-stream schedule active (several micro-batches per rank, --overlap 1) the kernel shares
+               the CUs with the other stream in the timed region, so the durations come from one extra
+               single-stream step after it and both averages are reported.
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
                (one 8-frame clip at full resolution, ~10 s) on the box's host cores.
@@ -42,7 +45,7 @@ torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
 
 # HBM-side traffic of one MSDA encoder-geometry launch, per frame, from the PMC passes committed in
-# profiles/r01_pmc_msda_fused_enc_N8.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 8 frames, the
+# profiles/r01_pmc_msda_level_N8.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 8 frames, the
 # factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
 MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
 
