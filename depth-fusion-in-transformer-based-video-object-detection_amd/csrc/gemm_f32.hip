@@ -5,14 +5,17 @@
 //   workgroup = 256 threads = 4 waves laid out WM x WN over a BM x BN output tile; a wave owns
 //   (BM/WM) x (BN/WN) = MT x NT MFMA tiles of 32 x 32, i.e. MT*NT*16 accumulator registers per lane
 //   K is walked in steps of BK = 16 through a double-buffered LDS stage:
-//     As[buf][k][m]  - A (and Linear weights) arrive K-contiguous as 16-byte loads and are
-//                      transposed on the way in (4 scalar LDS stores; row pitch BM+2 keeps the
-//                      stores and the 32-lane fragment reads conflict-free)
+//     As[buf][m][k]  - A (and Linear weights, Bs[buf][n][k]) arrive K-contiguous as 16-byte loads and
+//                      are stored as they are, one ds_write_b128 each; row pitch BK+4 floats = five
+//                      16-byte slots, so the 16 lanes of a ds_read_b128 group (16 different rows, the
+//                      same k) fall on 16 different slots
 //     Bs[buf][k][n]  - activations of a 1x1 convolution are already [K][N]: 16-byte LDS stores
 //   the next K-step's global loads are issued into registers before the 8 x MT*NT MFMAs of the
 //   current step, and written to the other LDS buffer after them: one barrier per K-step
-//   fragments: lane l reads A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31] with one ds_read_b32
-//   each - 4 LDS reads per 4 MFMAs (256 matrix-pipe cycles) for the 2 x 2 wave tile
+//   fragments: the MFMA sums over k in any order as long as A and B agree, so the 8 MFMAs of a
+//   K-step are numbered q = 4j + t and lane l (row/col l&31, half h = l>>5) feeds MFMA q with
+//   k = 8j + 4h + t: one ds_read_b128 at [row][8j + 4h] yields the lane's operand of FOUR MFMAs
+//   (the [K][N] operand reads the same k with ds_read_b32, as its rows run along n)
 //   epilogue straight from the accumulators (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31):
 //   + bias (per row for convolutions, per column for Linear), + residual, ReLU, zeroing of masked
 //   rows; every store instruction writes 2 rows x 128 contiguous bytes.
@@ -48,15 +51,16 @@ template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
-    constexpr int LDA = BM + 2;                       // [k][m] pitch: conflict-free transposed stores
-    constexpr int LDB = B_KN ? BN + 4 : BN + 2;       // [k][n] pitch (16-byte aligned rows when B_KN)
+    constexpr int LDK = BK + 4;                       // [m][k] / [n][k] pitch: 5 (BK = 16) sixteen-byte slots
+    constexpr int LDB = BN + 4;                       // [k][n] pitch of the [K][N] operand (16-byte aligned rows)
     constexpr int KQ = BK / 4;                        // float4 per row per K-step
     constexpr int A_F4 = BM * KQ, B_F4 = BN * KQ;     // (= BK * BN / 4 for the [K][N] operand as well)     // float4 per K-step in the A / B tile
     constexpr int A_LOADS = (A_F4 + 255) / 256;       // ... per thread (last pass may be partial)
     constexpr int B_LOADS = (B_F4 + 255) / 256;
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad wave layout");
-    __shared__ float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    static_assert(BK % 8 == 0, "a ds_read_b128 covers 8 consecutive k (4 per lane half)");
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_KN ? BK * LDB : BN * LDK];   // [k][n] or [n][k]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -117,10 +121,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             float4 v = ra[i];
             if (A2) { v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w; }
             if (!oka[i]) v = zero4;
-            As[buf][kq * 4 + 0][row] = v.x;
-            As[buf][kq * 4 + 1][row] = v.y;
-            As[buf][kq * 4 + 2][row] = v.z;
-            As[buf][kq * 4 + 3][row] = v.w;
+            *reinterpret_cast<float4 *>(&As[buf][row][kq * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
@@ -129,13 +130,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             const float4 v = okb[i] ? rb[i] : zero4;
             if (B_KN) {
                 const int kr = f / (BN / 4), nq = f % (BN / 4);
-                *reinterpret_cast<float4 *>(&Bs[buf][kr][nq * 4]) = v;
+                *reinterpret_cast<float4 *>(&Bs[buf][kr * LDB + nq * 4]) = v;
             } else {
                 const int row = f / KQ, kq = f % KQ;
-                Bs[buf][kq * 4 + 0][row] = v.x;
-                Bs[buf][kq * 4 + 1][row] = v.y;
-                Bs[buf][kq * 4 + 2][row] = v.z;
-                Bs[buf][kq * 4 + 3][row] = v.w;
+                *reinterpret_cast<float4 *>(&Bs[buf][row * LDK + kq * 4]) = v;
             }
         }
     };
@@ -147,29 +145,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     for (int t = 0; t < steps; ++t) {
         const int buf = t & 1;
         if (t + 1 < steps) load_tiles((t + 1) * BK);          // in flight during the MFMAs below
-        // fragments of k-pair kk+1 are read while the MFMAs of k-pair kk run
-        float a[2][MT], b[2][NT];
+        // A fragments (and B's for the [N][K] operand): one 16-byte read per lane per 4 MFMAs
+        constexpr int KJ = BK / 8;
+        float4 af[KJ][MT], bf[KJ][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[0][i] = As[buf][half][wm * TM + i * 32 + c];
+        for (int j = 0; j < KJ; ++j) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[0][j] = Bs[buf][half][wn * TN + j * 32 + c];
+            for (int i = 0; i < MT; ++i)
+                af[j][i] = *reinterpret_cast<const float4 *>(&As[buf][wm * TM + i * 32 + c][j * 8 + half * 4]);
+            if (!B_KN) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[nxt][i] = As[buf][kk * 2 + 2 + half][wm * TM + i * 32 + c];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[nxt][j] = Bs[buf][kk * 2 + 2 + half][wn * TN + j * 32 + c];
+                for (int jn = 0; jn < NT; ++jn)
+                    bf[j][jn] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * TN + jn * 32 + c) * LDK + j * 8 + half * 4]);
             }
-            // keep the LDS reads of the next k-pair AHEAD of this k-pair's MFMAs (left alone, the scheduler
+        }
+        float bs[2][NT];                                        // [K][N] operand: scalar reads, one MFMA ahead
+        if (B_KN) {
+#pragma unroll
+            for (int jn = 0; jn < NT; ++jn) bs[0][jn] = Bs[buf][(half * 4) * LDB + wn * TN + jn * 32 + c];
+        }
+#pragma unroll
+        for (int q = 0; q < BK / 2; ++q) {
+            const int j = q >> 2, tt = q & 3, cur = q & 1, nxt = cur ^ 1;
+            if (B_KN && q + 1 < BK / 2) {
+                const int kn = ((q + 1) >> 2) * 8 + half * 4 + ((q + 1) & 3);
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) bs[nxt][jn] = Bs[buf][kn * LDB + wn * TN + jn * 32 + c];
+            }
+            // keep the LDS reads of the next MFMA group AHEAD of this group's MFMAs (left alone, the scheduler
             // reuses the fragment registers and sinks the reads below the MFMAs, exposing their latency)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+                const float av = tt == 0 ? af[j][i].x : tt == 1 ? af[j][i].y : tt == 2 ? af[j][i].z : af[j][i].w;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                for (int jn = 0; jn < NT; ++jn) {
+                    const float bv = B_KN ? bs[cur][jn]
+                                          : (tt == 0 ? bf[j][jn].x : tt == 1 ? bf[j][jn].y : tt == 2 ? bf[j][jn].z : bf[j][jn].w);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < steps) store_tiles(buf ^ 1);
@@ -252,6 +267,7 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         if (force[0] == '2') return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
         if (force[0] == '3') return launch<64, 128, 1, 4, 32>(g, batch, b_is_kn, st);
         if (force[0] == '4') return launch<128, 128, 2, 2, 32>(g, batch, b_is_kn, st);
+        if (force[0] == '5') return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     }
     if (M <= 64) return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
     if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
