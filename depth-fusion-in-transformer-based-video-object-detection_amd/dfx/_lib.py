@@ -18,7 +18,6 @@ SIGNATURES = {
     "dfx_msda_fused_forward_f32": [_p, _p, _p, _p, _i, _i, _p, _l, _p, _l] + _DIMS + [_p, _p],
     "dfx_profile_enable": [_i],
     "dfx_profile_drain": [_p, _p, _p, _p, _i],
-    "dfx_msda_fused_tile_forward_f32": [_p, _p, _i, _p, _l, _p, _l, _i, _i, _i, _p, _p],
     "dfx_msda_fused_level_fits": [_i, _i],
     "dfx_msda_fused_level_forward_f32": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     # include/dfx_roi.h: input, rois, N, C, H, W, K, ph, pw, scale, sampling_ratio, aligned, out, stream

@@ -13,16 +13,14 @@ from . import _lib
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
 
-# Switch for the LDS-tiled kernel of the encoder geometry (csrc/msda_tile.hip).  Results are
-# identical either way; as measured in round 1 it only ties the wave-per-query kernel when all
-# samples stay inside the staged halo and loses otherwise, so it is opt-in.
-USE_TILE_KERNEL = os.environ.get("DFX_MSDA_TILE", "0") == "1"
-
 # Single-level attention with many queries (encoder, depth fusion) runs on the level-in-LDS kernel
 # (csrc/msda_level.hip) when the level fits the CU's LDS; DFX_MSDA_LEVEL=0 keeps the wave-per-query
 # kernel (A/B measurements).  LEVEL_MIN_QUERIES: below it staging the level costs more than it saves.
 USE_LEVEL_KERNEL = os.environ.get("DFX_MSDA_LEVEL", "1") == "1"
 LEVEL_MIN_QUERIES = 1024
+# msda_fused_forward takes operands in the reference layouts, where the level kernel is slower than the
+# wave-per-query kernel (33 vs 26 us at the encoder geometry): it uses it only when this is set (parity tests).
+LEVEL_ON_REFERENCE_LAYOUTS = False
 
 # Measurement hook (bench.py): profile_start() makes every fused MSDA kernel stamp its own begin / end
 # timestamps (include/dfx_msda.h, dfx_profile_*); profile_stop() returns [(seconds, algorithmic_bytes,
@@ -153,8 +151,7 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     base = qproj.data_ptr()
     host = getattr(spatial_shapes, "_dfx_host", None)
-    tile = USE_TILE_KERNEL and host is not None and L == 1 and Lr == 1 and Lq == S == host[0][0] * host[0][1]
-    level = (USE_LEVEL_KERNEL and not tile and host is not None and L == 1 and Lr == 1 and M == 8 and D == 32
+    level = (USE_LEVEL_KERNEL and LEVEL_ON_REFERENCE_LAYOUTS and host is not None and L == 1 and Lr == 1 and M == 8 and D == 32
              and P == 4 and S == host[0][0] * host[0][1] and Lq >= LEVEL_MIN_QUERIES
              and lib.dfx_msda_fused_level_fits(host[0][0], host[0][1]))
     with torch.cuda.device(value.device):
@@ -164,10 +161,6 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
             rc = lib.dfx_msda_fused_level_forward_f32(
                 value.data_ptr(), reference_points.data_ptr(), ref_dim, base, base + 2 * mlp * 4, ctypes.byref(ly),
                 N, host[0][0], host[0][1], Lq, out.data_ptr(), _stream(value.device))
-        elif tile:   # encoder / depth-fusion geometry: queries are the pixels of the (single) value map
-            rc = lib.dfx_msda_fused_tile_forward_f32(
-                value.data_ptr(), reference_points.data_ptr(), ref_dim, base, 3 * mlp, base + 2 * mlp * 4, 3 * mlp,
-                N, host[0][0], host[0][1], out.data_ptr(), _stream(value.device))
         else:
             rc = lib.dfx_msda_fused_forward_f32(
                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),

@@ -117,19 +117,6 @@ int dfx_msda_fused_forward_f32(const float *value, const int64_t *shapes, const 
                                float *out, void *stream);
 
 /*
- * The same fused operator for the encoder / depth-fusion geometry, LDS-tiled (csrc/msda_tile.hip):
- * one level (L = 1, P = 4, M = 8, D = 32), queries in raster order over the same H x W grid as
- * the value map (Lq == H*W), one reference level.  H and W are HOST integers here (the grid and
- * the LDS window are sized from them).  Results equal dfx_msda_fused_forward_f32 for any offsets:
- * corners outside a tile's staged window are fetched from global memory.
- *   value [N,H*W,8,32]; ref [N,H*W,1,ref_dim]; off / logits as above; out [N,H*W,256]
- */
-int dfx_msda_fused_tile_forward_f32(const float *value, const float *ref, int ref_dim,
-                                    const float *off, long off_stride,
-                                    const float *logits, long logit_stride,
-                                    int N, int H, int W, float *out, void *stream);
-
-/*
  * The same fused operator for single-level attention with the whole level resident in LDS
  * (csrc/msda_level.hip): L = 1, one reference level, P = 4, M = 8, D = 32, any Lq.  A workgroup
  * stages 8 channels of one head of every token of the H x W map (zero-bordered) into LDS and the

@@ -266,46 +266,6 @@ def test_fused_front_end_temporal_quirk(msda, oracle):
     assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
 
 
-# ---- LDS-tiled kernel of the encoder geometry (csrc/msda_tile.hip) -----------------------------
-@pytest.mark.parametrize("H,W,N,ref_dim,spread", [
-    (50, 84, 2, 2, 3.0),      # production map, offsets of a few pixels (all corners inside the halo)
-    (50, 84, 1, 2, 30.0),     # large offsets: most corners take the global-memory fallback
-    (13, 21, 3, 2, 4.0), (7, 9, 2, 4, 2.0), (1, 1, 2, 2, 1.0), (33, 5, 1, 2, 6.0), (50, 84, 1, 4, 8.0),
-])
-def test_tile_kernel_matches_oracle(msda, oracle, H, W, N, ref_dim, spread):
-    from dfx import ops
-    from models.transformer_layers import make_level_tensors
-    g = torch.Generator().manual_seed(H * 131 + W)
-    M, D, P, S = 8, 32, 4, H * W
-    shapes, lsi = make_level_tensors([(H, W)], "cuda")
-    value = torch.randn(N, S, M, D, generator=g)
-    qproj = torch.randn(N, S, 3 * M * P, generator=g)
-    qproj[..., : 2 * M * P] *= spread
-    ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
-    grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1).view(1, S, 1, 2).expand(N, S, 1, 2)
-    if ref_dim == 2:
-        ref = grid.contiguous()
-        norm = torch.tensor([W, H], dtype=torch.float32)
-        off = qproj[..., : 2 * M * P].reshape(N, S, M, 1, P, 2)
-        loc = ref[:, :, None, :, None, :] + off / norm
-    else:
-        ref = torch.cat([grid, torch.rand(N, S, 1, 2, generator=g) * 0.5], -1).contiguous()
-        off = qproj[..., : 2 * M * P].reshape(N, S, M, 1, P, 2)
-        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
-    aw = torch.softmax(qproj[..., 2 * M * P:].reshape(N, S, M, P), -1).view(N, S, M, 1, P)
-    expect = oracle.msda_forward(value, shapes.cpu(), lsi.cpu(), loc.contiguous(), aw)
-    saved = ops.USE_TILE_KERNEL
-    try:
-        ops.USE_TILE_KERNEL = True
-        got = ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, P)
-        ops.USE_TILE_KERNEL = False      # the wave-per-query kernel on the same inputs
-        plain = ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, P)
-    finally:
-        ops.USE_TILE_KERNEL = saved
-    assert torch.allclose(got.cpu(), expect, rtol=1e-4, atol=5e-5)
-    assert torch.allclose(got, plain, rtol=1e-5, atol=1e-5)
-
-
 # ---- level-in-LDS kernel for single-level attention (csrc/msda_level.hip) ------------------------
 def _level_case(seed, H, W, N, Lq, ref_dim, spread, raster):
     g = torch.Generator().manual_seed(seed)
@@ -339,12 +299,12 @@ def _run_level(value, qproj, ref, H, W, level):
     from dfx import ops
     from models.transformer_layers import make_level_tensors
     shapes, lsi = make_level_tensors([(H, W)], "cuda")
-    saved = ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES
+    saved = ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES, ops.LEVEL_ON_REFERENCE_LAYOUTS
     try:
-        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES = level, 0
+        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES, ops.LEVEL_ON_REFERENCE_LAYOUTS = level, 0, True
         return ops.msda_fused_forward(value.cuda(), shapes, lsi, ref.cuda(), qproj.cuda(), 1, 4)
     finally:
-        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES = saved
+        ops.USE_LEVEL_KERNEL, ops.LEVEL_MIN_QUERIES, ops.LEVEL_ON_REFERENCE_LAYOUTS = saved
 
 
 def _run_level_blocked(value, qproj, ref, H, W):

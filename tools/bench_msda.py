@@ -14,7 +14,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd"))
 import MultiScaleDeformableAttention as MSDA  # noqa: E402
-from dfx import ops  # noqa: E402
+from dfx import ops
+ops.LEVEL_ON_REFERENCE_LAYOUTS = True      # these probes compare the kernels on the reference layouts too  # noqa: E402
 
 
 def timeit(fn, iters):
@@ -73,11 +74,11 @@ def main():
             for spread in (1.0, 3.0):
                 q2 = qproj.clone()
                 q2[..., : 2 * M * L * P] *= spread
-                for mode in ("wave", "level", "tile"):
-                    ops.USE_TILE_KERNEL, ops.USE_LEVEL_KERNEL = mode == "tile", mode == "level"
+                for mode in ("wave", "level"):
+                    ops.USE_LEVEL_KERNEL = mode == "level"
                     tt = timeit(lambda: ops.msda_fused_forward(value, sh2, lsi2, grid, q2, L, P), a.iters)
                     line += f" | sd{spread:.0f}px {mode} {tt*1e6:7.1f} us {nbytes/tt/1e9:7.1f} GB/s"
-                ops.USE_TILE_KERNEL, ops.USE_LEVEL_KERNEL = False, True
+                ops.USE_LEVEL_KERNEL = True
         print(line, flush=True)
 
 

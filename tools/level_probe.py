@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 
 from dfx import ops
+ops.LEVEL_ON_REFERENCE_LAYOUTS = True      # these probes compare the kernels on the reference layouts too
 from models.transformer_layers import make_level_tensors
 
 
