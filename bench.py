@@ -115,6 +115,9 @@ def main():
                          "tail of micro-batch i (ClipRunner; same results)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="ask MIOpen for run-to-run deterministic convolution solvers (costs ~6 %% here)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank "
+                         "code path with several ranks on one GPU)")
     ap.add_argument("--conv-autotune", type=int, default=0,
                     help="let MIOpen time its fp32 solvers per convolution shape during warm-up (cudnn.benchmark)")
     a = ap.parse_args()
@@ -126,12 +129,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the operators have no CPU path)")
+    if a.backend != "nccl":                       # rehearsal: several ranks may share one GPU
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     torch.backends.cudnn.benchmark = bool(a.conv_autotune)
     torch.backends.cudnn.deterministic = bool(a.deterministic)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)          # RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)      # RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend)
     assert a.frames % world == 0, "the clip must split evenly over the ranks"
     per_rank = a.frames // world
 
