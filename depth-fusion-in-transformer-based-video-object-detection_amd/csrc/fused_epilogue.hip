@@ -141,6 +141,41 @@ extern "C" int dfx_bias_relu_maxpool_f32(const float *x, const float *bias, floa
     return dfx::check_launch("bias_relu_maxpool");
 }
 
+// Box refinement of the iterative decoders in one pass (8 elementwise launches in the reference's
+// formulation): out = sigmoid(delta + inverse_sigmoid(ref)) on the first ref_dim of the 4 box columns,
+// sigmoid(delta) on the rest; inverse_sigmoid as util/misc.py:55-58 (clamp to [0,1], eps = 1e-5 floors).
+__global__ __launch_bounds__(256) void box_refine(const float4 *__restrict__ delta, const float *__restrict__ ref,
+                                                  int ref_dim, float4 *__restrict__ out, long rows, float eps)
+{
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float4 d = delta[r];
+    float v[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c < ref_dim) {
+            float x = ref[r * ref_dim + c];
+            x = fminf(fmaxf(x, 0.f), 1.f);
+            v[c] += logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+        }
+        v[c] = 1.f / (1.f + expf(-v[c]));
+    }
+    out[r] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int dfx_box_refine_f32(const float *delta, const float *ref, int ref_dim, float *out, long rows, float eps,
+                                  void *stream)
+{
+    if (rows < 0 || (ref_dim != 2 && ref_dim != 4)) return dfx::fail(DFX_EINVAL, "box_refine: bad dimension");
+    if (rows == 0) return DFX_OK;
+    if (!delta || !ref || !out) return dfx::fail(DFX_EINVAL, "box_refine: null pointer");
+    if (!dfx::aligned16(delta) || !dfx::aligned16(out)) return dfx::fail(DFX_EINVAL, "box_refine: buffers must be 16-byte aligned");
+    if ((rows + 255) / 256 >= (1L << 31)) return dfx::fail(DFX_ERANGE, "box_refine: too many rows");
+    hipLaunchKernelGGL(box_refine, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4 *>(delta), ref, ref_dim, reinterpret_cast<float4 *>(out), rows, eps);
+    return dfx::check_launch("box_refine");
+}
+
 extern "C" int dfx_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,
                                      float *out, long rows, int C, float eps, void *stream)
 {

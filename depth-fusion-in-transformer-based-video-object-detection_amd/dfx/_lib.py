@@ -31,6 +31,7 @@ SIGNATURES = {
     "dfx_bias_act_nchw_f32": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
     "dfx_bias_relu_maxpool_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "dfx_add_layernorm_f32": [_p, _p, _p, _p, _p, _l, _i, ctypes.c_float, _p],
+    "dfx_box_refine_f32": [_p, _p, _i, _p, _l, ctypes.c_float, _p],
 }
 
 

@@ -338,6 +338,24 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     return out
 
 
+def box_refine(delta, reference, eps=1e-5):
+    """sigmoid(delta + inverse_sigmoid(reference)) on the first reference.shape[-1] (2 or 4) of the 4 box
+    columns, sigmoid(delta) on the others, in one launch (include/dfx_fused.h).  delta [...,4]."""
+    lib = _lib.load()
+    delta, reference = delta.contiguous(), reference.contiguous()
+    _check_inputs([("delta", delta), ("reference", reference)])
+    rd = reference.shape[-1]
+    _require(delta.shape[-1] == 4 and rd in (2, 4) and delta.shape[:-1] == reference.shape[:-1]
+             and delta.dtype == torch.float32 and reference.dtype == torch.float32,
+             "box_refine: delta [...,4], reference [...,2|4], fp32")
+    out = torch.empty_like(delta)
+    with torch.cuda.device(delta.device):
+        rc = lib.dfx_box_refine_f32(delta.data_ptr(), reference.data_ptr(), rd, out.data_ptr(), delta.numel() // 4,
+                                    float(eps), _stream(delta.device))
+    _lib.check(rc, "box_refine")
+    return out
+
+
 def add_layernorm(x, residual, norm):
     """``norm(x + residual)`` for an nn.LayerNorm over the last dimension, in one pass
     (include/dfx_fused.h); residual may be None."""

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from util.memo import memo_on
 from util.misc import NestedTensor
 
 from .position_encoding import build_position_encoding
@@ -46,7 +47,8 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 def _resize_mask(m, size):
-    return F.interpolate(m[None].float(), size=size).to(torch.bool)[0]
+    size = tuple(int(v) for v in size)
+    return memo_on(m, ("resize_mask", size), lambda: F.interpolate(m[None].float(), size=size).to(torch.bool)[0])
 
 
 class FusionBackboneBase(nn.Module):

@@ -60,7 +60,8 @@ class ClipRunner:
         """frames [F,4|3,H,W] (this rank's frames) -> dict of per-frame tensors."""
         m, tr = self.model, self.model.transformer
         F_, _, H, W = frames.shape
-        if mask is None:
+        own_mask = mask is None
+        if own_mask:
             mask = self._cached(("mask", F_, H, W, str(frames.device)),
                                 lambda: torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device))
         whwh = self._cached(("whwh", W, H, str(frames.device)), lambda: torch.as_tensor(
@@ -69,7 +70,12 @@ class ClipRunner:
         meta = []
 
         def encode(sl):
-            return m._encode_inputs(NestedTensor(frames[sl], mask[sl]))
+            # the runner's own all-valid mask is handed over as the SAME tensor object on every call, so
+            # everything derived from it (resized masks, positional embeddings, valid ratios) is built once
+            # (util/memo.py); a caller's mask is passed through as it comes
+            msl = mask[sl] if not own_mask else self._cached(
+                ("mask_slice", F_, H, W, str(frames.device), sl.start, sl.stop), lambda: mask[sl])
+            return m._encode_inputs(NestedTensor(frames[sl], msl))
 
         def tail(enc):
             srcs, masks, pos, d_srcs, d_masks, d_pos, rgbd = enc

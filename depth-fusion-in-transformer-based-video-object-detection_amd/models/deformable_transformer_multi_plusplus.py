@@ -27,6 +27,7 @@ from util import box_ops
 from util.misc import inverse_sigmoid
 
 from .deformable_transformer_single import SpatialTransformerBase
+from .detector_common import apply_box_head
 from .roi_align import RoIAlign
 from .sparse_roi_head.head import RCNNHead
 from .transformer_layers import (DeformableTransformerDecoder, DeformableTransformerDecoderLayer,  # noqa: F401
@@ -102,7 +103,7 @@ class DeformableTransformer(SpatialTransformerBase):
         h, w = hw
         F_, Q, C = hs_last.shape
         logits = class_embed(hs_last)
-        boxes = (bbox_embed(hs_last) + inverse_sigmoid(ref_last)).sigmoid()
+        boxes = apply_box_head(bbox_embed, hs_last, ref_last)
         xyxy = box_ops.box_cxcywh_to_xyxy(boxes) * imgs_whwh                      # image pixels
         rois = bbox2roi([xyxy[f] for f in range(F_)])                             # [F*Q,5], image index = frame
         out = dict(logits=logits, boxes=boxes)
@@ -146,14 +147,8 @@ class DeformableTransformer(SpatialTransformerBase):
             cur_hs, refs = getattr(self, f"temporal_decoder{i + 1}")(
                 cur_hs, cur_reference_out, cur_memory, shapes1, lsi1, ratios, None, None)
             if i < 2:
-                box = temp_bbox_embed_list[i](cur_hs)
-                unact = inverse_sigmoid(refs)
-                if unact.shape[-1] == 4:
-                    box = box + unact
-                else:
-                    assert unact.shape[-1] == 2
-                    box[..., :2] += unact
-                aux.append({"pred_logits": temp_class_embed_list[i](cur_hs), "pred_boxes": box.sigmoid()})
+                aux.append({"pred_logits": temp_class_embed_list[i](cur_hs),
+                            "pred_boxes": apply_box_head(temp_bbox_embed_list[i], cur_hs, refs)})
             else:
                 final_hs, final_refs = cur_hs, refs
         return final_hs, final_refs, aux, picks

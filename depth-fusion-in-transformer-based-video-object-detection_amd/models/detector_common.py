@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from util import box_ops
+from util.memo import memo_on
 from util.misc import NestedTensor, inverse_sigmoid
 
 
@@ -27,10 +28,17 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 4 == 0
+        if fused:
+            from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue: one launch per layer
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i < self.num_layers - 1:
-                x = F.relu(x)
+            last = i == self.num_layers - 1
+            if fused and not last and layer.in_features % 4 == 0:
+                x = _ops.linear(x.contiguous(), layer.weight, layer.bias, relu=True)
+            else:
+                x = layer(x)
+                if not last:
+                    x = F.relu(x)
         return x
 
 
@@ -50,6 +58,9 @@ def _zero_last_layer(mlp):
 def apply_box_head(bbox_embed, hs, reference):
     """sigmoid(MLP(hs) + inverse_sigmoid(reference)), reference being 2-d points or 4-d boxes."""
     box = bbox_embed(hs)
+    if box.is_cuda and box.dtype == torch.float32 and not (torch.is_grad_enabled() and (box.requires_grad or reference.requires_grad)):
+        from dfx import ops as _ops
+        return _ops.box_refine(box, reference)
     unact = inverse_sigmoid(reference)
     if unact.shape[-1] == 4:
         box = box + unact
@@ -163,7 +174,9 @@ class DetectorBase(nn.Module):
             masks.append(mask)
         for l in range(len(srcs), self.num_feature_levels):     # extra stride-2 levels
             src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
-            mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+            size = tuple(int(v) for v in src.shape[-2:])
+            mask = memo_on(samples.mask, ("resize_mask", size),
+                           lambda: F.interpolate(samples.mask[None].float(), size=size).to(torch.bool)[0])
             srcs.append(src)
             masks.append(mask)
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))

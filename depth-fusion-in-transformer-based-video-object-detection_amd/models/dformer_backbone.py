@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from util.memo import memo_on
 from util.misc import NestedTensor
 
 from .position_encoding import build_position_encoding
@@ -40,6 +41,11 @@ class DownsamplePath(nn.Module):
             for p in layer.parameters():
                 p.requires_grad = False
         return layer
+
+
+def _resize_mask(m, size):
+    size = tuple(int(v) for v in size)
+    return memo_on(m, ("resize_mask", size), lambda: F.interpolate(m[None].float(), size=size).to(torch.bool)[0])
 
 
 class DFormerBackbone(nn.Module):
@@ -72,9 +78,9 @@ class DFormerBackbone(nn.Module):
         for i, stage in enumerate(stages):
             x = stage(x)
             if self.return_interm_layers:
-                out[str(i)] = NestedTensor(x, F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0])
+                out[str(i)] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))
         if not self.return_interm_layers:
-            out["0"] = NestedTensor(x, F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0])
+            out["0"] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))
         return out
 
     def load_pretrained_weights(self, model, pretrained_weights_path, prefix="downsample_layers_e"):

@@ -4,6 +4,7 @@ import math
 import torch
 from torch import nn
 
+from util.memo import memo_on
 from util.misc import NestedTensor
 
 
@@ -21,6 +22,10 @@ class PositionEmbeddingSine(nn.Module):
     def forward(self, tensor_list: NestedTensor):
         mask = tensor_list.mask
         assert mask is not None
+        return memo_on(mask, ("pos_sine", self.num_pos_feats, self.temperature, self.normalize, self.scale),
+                       lambda: self._encode(mask))
+
+    def _encode(self, mask):
         valid = ~mask
         ys = valid.cumsum(1, dtype=torch.float32)
         xs = valid.cumsum(2, dtype=torch.float32)

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from models.ops.modules import MSDeformAttn
+from util.memo import memo_on
 from util.misc import inverse_sigmoid
 
 
@@ -81,6 +82,10 @@ def host_shapes(spatial_shapes):
 
 def get_valid_ratio(mask):
     """Fraction of each padded map that is image: [N,2] = (w_ratio, h_ratio)."""
+    return memo_on(mask, "valid_ratio", lambda: _valid_ratio(mask))
+
+
+def _valid_ratio(mask):
     _, H, W = mask.shape
     valid_h = torch.sum(~mask[:, :, 0], 1)
     valid_w = torch.sum(~mask[:, 0, :], 1)
@@ -296,7 +301,8 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
 def _scale_reference(reference_points, valid_ratios):
     if reference_points.shape[-1] == 4:
-        return reference_points[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+        vr4 = memo_on(valid_ratios, "vr4", lambda: torch.cat([valid_ratios, valid_ratios], -1)[:, None])
+        return reference_points[:, :, None] * vr4
     assert reference_points.shape[-1] == 2
     return reference_points[:, :, None] * valid_ratios[:, None]
 
@@ -318,6 +324,9 @@ class DeformableTransformerDecoder(nn.Module):
         if self.bbox_embed is None:
             return reference_points
         delta = self.bbox_embed[lid](output)
+        if delta.is_cuda and delta.dtype == torch.float32 and not torch.is_grad_enabled():
+            from dfx import ops as _ops            # sigmoid(delta + inverse_sigmoid(ref)) in one launch
+            return _ops.box_refine(delta, reference_points)
         if reference_points.shape[-1] == 4:
             new = delta + inverse_sigmoid(reference_points)
         else:

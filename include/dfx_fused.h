@@ -35,6 +35,14 @@ int dfx_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int
 int dfx_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
                           long rows, int C, float eps, void *stream);
 
+/* Box refinement of the iterative decoders and detection heads in one pass:
+ *   out[r,c] = sigmoid(delta[r,c] + inverse_sigmoid(ref[r,c]))  for c < ref_dim,  sigmoid(delta[r,c]) otherwise,
+ * inverse_sigmoid(x) = log(max(clamp(x,0,1), eps) / max(1 - clamp(x,0,1), eps))
+ * (/root/reference/util/misc.py inverse_sigmoid; deformable_transformer_single.py:724-735,
+ * deformable_detr_single.py:203-212).  delta, out [rows,4]; ref [rows,ref_dim], ref_dim 2 or 4. */
+int dfx_box_refine_f32(const float *delta, const float *ref, int ref_dim, float *out, long rows, float eps,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

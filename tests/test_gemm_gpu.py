@@ -101,3 +101,24 @@ def test_stem_epilogue_matches_torch(shape):
     b = torch.randn(shape[1], generator=g).cuda()
     want = torch.nn.functional.max_pool2d((x + b.view(1, -1, 1, 1)).relu(), 3, 2, 1)
     assert torch.equal(ops.bias_relu_maxpool(x, b), want)
+
+
+@pytest.mark.parametrize("rows,ref_dim", [(300, 4), (2400, 2), (1, 4), (777, 2)])
+def test_box_refine_matches_torch(rows, ref_dim):
+    """sigmoid(delta + inverse_sigmoid(ref)) in one launch vs the reference's chain of elementwise ops
+    (util/misc.py inverse_sigmoid), incl. references at / beyond 0 and 1."""
+    from dfx import ops
+    from util.misc import inverse_sigmoid
+    g = torch.Generator().manual_seed(rows + ref_dim)
+    delta = (torch.randn(rows, 4, generator=g) * 2).cuda()
+    ref = torch.rand(rows, ref_dim, generator=g)
+    ref.view(-1)[::7] = 0.0
+    ref.view(-1)[3::11] = 1.0
+    ref.view(-1)[5::13] = 1.2
+    ref.view(-1)[6::17] = -0.1
+    ref = ref.cuda()
+    want = delta.clone()
+    want[..., :ref_dim] += inverse_sigmoid(ref)
+    want = want.sigmoid()
+    got = ops.box_refine(delta, ref)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)

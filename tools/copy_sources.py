@@ -1,0 +1,70 @@
+"""Where do the small elementwise / copy kernels of a rank step come from?  torch.profiler with Python
+stacks, grouped by the innermost frame inside this repository.
+
+    python tools/copy_sources.py [frames=4]
+"""
+import collections
+import os
+import sys
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd"))
+sys.path.insert(0, ROOT)
+from bench import build  # noqa: E402
+from models.clip_inference import ClipRunner  # noqa: E402
+
+F_ = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+T = 32
+dev = torch.device("cuda")
+model = build(dev, T - 1)
+runner = ClipRunner(model, micro_batch=F_)
+x = torch.randn(F_, 4, 800, 1333, device=dev)
+
+
+def step():
+    local = runner.frames_forward(x)
+    rep = T // F_
+    return runner.temporal_forward(local, local["ref"].repeat(rep, 1, 1), local["logits"].repeat(rep, 1, 1), 0)
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+import traceback  # noqa: E402
+
+from torch.overrides import TorchFunctionMode  # noqa: E402
+
+WATCH = {"contiguous", "clone", "to", "cat", "stack", "repeat", "add", "mul", "div", "sub", "clamp", "sigmoid", "log",
+         "masked_fill", "gather", "index_select", "__getitem__", "__setitem__", "flatten", "permute", "transpose",
+         "reshape", "float", "type", "copy_", "expand", "where", "topk", "sort", "__add__", "__mul__", "__truediv__",
+         "__sub__", "__radd__", "__rmul__", "relu", "softmax", "layer_norm", "linear", "exp", "neg", "zeros", "ones",
+         "full", "arange", "as_tensor", "tensor", "__rsub__", "unbind", "split", "chunk", "sum", "mean", "max", "min"}
+count = collections.Counter()
+
+
+class Spy(TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", str(func))
+        if name in WATCH:
+            site = "?"
+            for fr in reversed(traceback.extract_stack(limit=12)[:-1]):
+                if "depth-fusion-in-transformer" in fr.filename and "tools/" not in fr.filename:
+                    site = fr.filename.split("_amd/")[-1] + ":" + str(fr.lineno)
+                    break
+            count[(name, site)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Spy():
+    step()
+    torch.cuda.synchronize()
+tot = collections.Counter()
+for (name, site), c in count.items():
+    tot[site] += c
+print("calls per site (all watched ops):")
+for site, c in tot.most_common(45):
+    names = ", ".join(f"{n}x{k}" for (n, s2), k in count.items() if s2 == site)
+    print(f"{c:5d}  {site:60s} {names[:120]}")
