@@ -103,6 +103,32 @@ def test_detector_gpu_vs_cpu_oracle_and_box_indices(oracle, monkeypatch):
             assert set(a.tolist()) == set(b.tolist())
 
 
+@pytest.mark.parametrize("H,W,T", [
+    (70, 118, 3),        # feature map 5 x 8: H*W not a multiple of 4 -> the library-convolution fall-backs of the backbone
+    (1216, 1600, 2),     # feature map 76 x 100 = 7600 tokens: too large for the level-in-LDS kernel -> wave-per-query kernel
+])
+@pytest.mark.timeout(900)
+def test_detector_other_resolutions_gpu_vs_cpu_oracle(H, W, T):
+    """The same GPU-vs-CPU-oracle comparison at resolutions that leave the fast paths of the default
+    800 x 1333 configuration (shape guards in models/resnet.py, dfx/ops.py:level_supported)."""
+    from models.clip_inference import ClipRunner
+    clip = _clip(T, 31, H, W)
+    gpu_model, _ = _build("cuda")
+    got = ClipRunner(gpu_model.cuda(), micro_batch=T)(clip.cuda())
+    import models.ops.functions.ms_deform_attn_func as f
+    from dfx import ops
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    saved = (f.MSDeformAttnFunction, ops.roi_align)
+    try:
+        _patch_cpu_ops()
+        cpu_model, _ = _build("cpu")
+        want = ClipRunner(cpu_model, micro_batch=T)(clip)
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    assert (got["pred_logits"].cpu() - want["pred_logits"]).abs().max() < 1e-3
+    assert (got["pred_boxes"].cpu() - want["pred_boxes"]).abs().max() < 1e-3
+
+
 def test_roi_align_kernels_match_oracle(oracle):
     from dfx import ops
     g = torch.Generator().manual_seed(4)
