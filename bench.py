@@ -23,7 +23,7 @@ The JSON line also carries
                single-stream step after it and both averages are reported.
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
-               (one 8-frame clip at full resolution, ~10 s) on the box's host cores.
+               (one 12-frame clip at full resolution, ~12 s) on the box's host cores.
 """
 import argparse
 import json
@@ -64,7 +64,7 @@ def build(device, num_ref_frames):
     return model.to(device).eval()
 
 
-def cpu_baseline(height, width, threads, frames=8):
+def cpu_baseline(height, width, threads, frames=12):
     """The same host code on CPU tensors, the oracle as the MSDA / RoIAlign operator."""
     from oracle import msda_oracle
     import models.ops.functions.ms_deform_attn_func as f
