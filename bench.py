@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="two-stream schedule inside a rank: backbones of micro-batch i+1 beside the transformer "
                          "tail of micro-batch i (ClipRunner; same results)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="clips are a stream: queue each step with ClipRunner.submit, so the transformer tail of clip k "
+                         "runs on a second HIP stream beside the backbones of clip k+1 (same results; 0 = one clip at a "
+                         "time on one stream; 1 = on for a single GPU; 2 = on for N > 1 as well)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="ask MIOpen for run-to-run deterministic convolution solvers (costs ~6 %% here)")
     ap.add_argument("--backend", default="nccl",
@@ -152,6 +156,10 @@ def main():
     runner = ClipRunner(model, micro_batch=min(a.micro_batch, per_rank), overlap=bool(a.overlap))
     n_micro = -(-per_rank // min(a.micro_batch, per_rank))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
+    # N > 1: the exchange would sit on the side stream; that is how torch.distributed's NCCL backend is meant to be
+    # used, but it could not be exercised on RCCL in this round (one GPU per session), so it needs --pipeline 2
+    pipelined = n_micro == 1 and (a.pipeline >= 2 or (a.pipeline == 1 and world == 1))
+    step = (lambda: runner.submit(mine)) if pipelined else (lambda: runner(mine))
 
     def barrier():
         if world > 1:
@@ -159,29 +167,29 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        runner(mine)
+        step()
     barrier()
     ops.profile_start()                                            # MSDA kernels stamp their own begin/end events
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        runner(mine)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     launches = ops.profile_stop()
     timed_region_launches = None
-    if overlapped:
+    if overlapped or pipelined:
         # In the timed region the MSDA kernel shares the CUs with the other stream's convolutions, so
         # its stamped duration there is not the kernel's own.  The roofline figures come from one extra
         # single-stream step (same inputs, same kernels) after the timed region; both are reported.
         timed_region_launches = launches
-        runner.overlap = False
+        saved_overlap, runner.overlap = runner.overlap, False
         runner(mine)
         barrier()
         ops.profile_start()
         runner(mine)
         barrier()
         launches = ops.profile_stop()
-        runner.overlap = True
+        runner.overlap = saved_overlap
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -205,7 +213,7 @@ def main():
             if timed_region_launches is not None:
                 shared = [sec for (sec, _, lq, s) in timed_region_launches if lq == s and sec > 0]
                 roof["measured"] = ("HIP events stamped by the launch, one extra single-stream step after the timed "
-                                    "region (two-stream schedule off)")
+                                    "region (two-stream schedule / clip pipeline off)")
                 roof["avg_launch_us_timed_region_shared_cus"] = round(sum(shared) / max(len(shared), 1) * 1e6, 2)
         line = {
             "metric": "frames/sec at 800x1333 RGB-D, TransVOD++ Late-Fusion", "value": round(fps, 3),
@@ -216,7 +224,7 @@ def main():
                                    f"all-current mode (R={a.frames - 1}), L=1 DC5 (S=4200), 300 queries, 3 classes",
                        "frames_per_gpu": per_rank, "micro_batch": min(a.micro_batch, per_rank),
                        "parallelism": f"frame-shard x{world} + 1 all-gather/clip",
-                       "two_stream_overlap": overlapped},
+                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined},
             "roofline": roof,
             "e2e": {"hbm_frac": round(fps / world * BYTES_PER_FRAME / HBM_PEAK, 4),
                     "fp32_mfma_frac": round(fps / world * FLOPS_PER_FRAME / FP32_MFMA_PEAK, 4),

@@ -55,6 +55,31 @@ class ClipRunner:
         return self._const[key]
 
     # ---- steps 1+2 for a block of frames -------------------------------------------------------
+    # the two halves of steps 1+2 for ALL frames of the block in one pass (what ``submit`` pipelines)
+    def _block_consts(self, frames, mask):
+        m = self.model
+        F_, _, H, W = frames.shape
+        dev = str(frames.device)
+        if mask is None:        # the runner's own all-valid mask: the same tensor object on every call (util/memo.py)
+            mask = self._cached(("mask", F_, H, W, dev), lambda: torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device))
+        whwh = self._cached(("whwh", W, H, dev), lambda: torch.as_tensor(
+            (W, H, W, H), dtype=torch.long, device=frames.device).repeat(1, m.num_queries, 1))
+        return mask, whwh
+
+    def _encode_block(self, frames, mask=None):
+        mask, whwh = self._block_consts(frames, mask)
+        return self.model._encode_inputs(NestedTensor(frames, mask)), whwh
+
+    def _tail_block(self, staged):
+        m, tr = self.model, self.model.transformer
+        (srcs, masks, pos, d_srcs, d_masks, d_pos, rgbd), whwh = staged
+        st = tr._spatial_stage(srcs, masks, pos, d_srcs, d_masks, d_pos, m.query_embed.weight, rgbd)
+        fs = tr.frame_stage(st["hs"][-1], st["inter_references"][-1], st["memory"], st["lvl_pos_embed_flatten"],
+                            st["last_hw"], whwh, m.class_embed[-1], m.bbox_embed[-1], roles=("cur", "ref"))
+        return {"cur": fs["cur"], "ref": fs["ref"], "logits": fs["logits"], "ref_last": st["inter_references"][-1],
+                "memory": st["memory"], "valid_ratios": st["valid_ratios"], "spatial_shapes": st["spatial_shapes"],
+                "level_start_index": st["level_start_index"]}
+
     @torch.no_grad()
     def frames_forward(self, frames, mask=None):
         """frames [F,4|3,H,W] (this rank's frames) -> dict of per-frame tensors."""
@@ -174,3 +199,46 @@ class ClipRunner:
         local = self.frames_forward(frames, mask)
         all_ref, all_logits = self.exchange(local["ref"], local["logits"])
         return self.temporal_forward(local, all_ref, all_logits, first_frame=rank * frames.shape[0])
+
+    # ---- a stream of clips ------------------------------------------------------------------------
+    @torch.no_grad()
+    def submit(self, frames, mask=None):
+        """Pipelined ``__call__`` for a stream of clips (serving): this clip's backbones are queued on one
+        HIP stream, its transformer / query-RoI fusion / exchange / temporal stage on a second one, so
+        the tail of clip k - many short kernels that leave most CUs idle - runs beside the backbones of
+        clip k+1.  Same kernels, same results; only the schedule changes.
+
+        -> (outputs, done): ``outputs`` as ``__call__``; they are valid once ``done`` (a HIP event) has
+        completed - ``done.synchronize()``, ``torch.cuda.current_stream().wait_event(done)`` or a device
+        synchronize.  At most two clips are in flight; a third submit waits for the oldest."""
+        if not frames.is_cuda:
+            out = self(frames, mask)
+            return out, None
+        dev = frames.device
+        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        if dev not in self._streams:
+            self._streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        s_back, s_tail = self._streams[dev]
+        inflight = self.__dict__.setdefault("_inflight", [])
+        while inflight and inflight[0][-1].query():
+            inflight.pop(0)
+        if len(inflight) >= 2:
+            inflight.pop(0)[-1].synchronize()
+        s_back.wait_stream(torch.cuda.current_stream(dev))           # the caller's frames
+        saved_overlap, self.overlap = self.overlap, False             # one schedule at a time
+        try:
+            with torch.cuda.stream(s_back):
+                staged = self._encode_block(frames, mask)
+                ready = torch.cuda.Event()
+                ready.record(s_back)
+            with torch.cuda.stream(s_tail):
+                s_tail.wait_event(ready)
+                local = self._tail_block(staged)
+                all_ref, all_logits = self.exchange(local["ref"], local["logits"])
+                out = self.temporal_forward(local, all_ref, all_logits, first_frame=rank * frames.shape[0])
+                done = torch.cuda.Event()
+                done.record(s_tail)
+        finally:
+            self.overlap = saved_overlap
+        inflight.append((frames, staged, local, out, done))           # cross-stream tensors stay referenced until done
+        return out, done

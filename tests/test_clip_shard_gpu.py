@@ -94,3 +94,26 @@ def test_two_stream_schedule_gives_identical_outputs():
                 assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = saved
+
+
+def test_clip_pipeline_submit_matches_call():
+    """ClipRunner.submit (backbones of clip k+1 on one HIP stream beside the tail of clip k on another, at
+    most two clips in flight) returns what __call__ returns, for a stream of different clips."""
+    from models.clip_inference import ClipRunner
+    model = _build()
+    clips = [torch.randn(4, 4, 64, 96, generator=torch.Generator().manual_seed(40 + i)).cuda() for i in range(5)]
+    saved = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True         # see test_two_stream_schedule_gives_identical_outputs
+    try:
+        runner = ClipRunner(model, micro_batch=4)
+        want = [runner(c) for c in clips]
+        torch.cuda.synchronize()
+        handles = [runner.submit(c) for c in clips]   # queued back to back, nothing waited for in between
+        for (out, done), ref in zip(handles, want):
+            done.synchronize()
+            for k in ("pred_logits", "pred_boxes"):
+                assert torch.equal(out[k], ref[k]), k
+            for a, b in zip(out["topk"], ref["topk"]):
+                assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = saved
