@@ -1,0 +1,139 @@
+// Fused scaled-dot-product attention for the 300-query layers (include/dfx_mha.h) on the gfx950 matrix
+// cores, fp32 (v_mfma_f32_32x32x2_f32), online softmax, nothing but the output leaves the CU.
+//
+// Wave = 32 queries of one (batch element, head); workgroup = WAVES waves sharing the key / value tiles
+// of 32 rows that all of them need (LDS, 8.5 KB).  Everything is computed TRANSPOSED so that no matrix
+// ever has to change its register layout between the two products:
+//
+//   S^T[key][query] = sum_d K[key][d] Q[query][d]      A = K tile (LDS), B = Q^T (registers, pre-scaled)
+//   O^T[d][query]  += sum_key V[key][d] P^T[key][query]  A = V^T (LDS),   B = P^T = exp(S^T - m) (registers)
+//
+// In the MFMA accumulator layout lane l owns COLUMN l&31 - here always a query - and 16 of the 32 rows
+// (keys of S^T / channels of O^T; lane half h = l>>5 owns rows (r&3)+8(r>>2)+4h of register r).  The
+// B operand of an MFMA takes from lane (column, h) the element of inner index 2u+h - or of ANY inner
+// index, as long as A pairs it with the same one.  So the 16 MFMAs of the second product are numbered
+// by the accumulator register r of S^T: lane (query, h) feeds p[r] as it stands, and A reads V of key
+// (r&3)+8(r>>2)+4h for that lane half.  Softmax state (running maximum m, denominator l) is per query
+// = per lane pair (l, l^32): one cross-lane exchange per tile for the maximum, one at the end for l;
+// rescaling O^T is a per-lane scalar multiply.  Likewise the first product sums d in the order
+// lane half 0: d = 0..15, half 1: d = 16..31, so a lane's 16 K operands are 4 ds_read_b128.
+#include "dfx_common.h"
+#include "dfx_mha.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int D = 32;          // head dimension
+constexpr int TK = 32;         // keys per tile
+constexpr int KP = 36;         // K tile row pitch (floats): 9 sixteen-byte slots, conflict-free ds_read_b128
+constexpr int WAVES = 2;       // 64 queries per workgroup
+
+__global__ __launch_bounds__(64 * WAVES) void mha_fwd(const float *__restrict__ q, long q_batch, long q_row,
+                                                      const float *__restrict__ k, long k_batch, long k_row,
+                                                      const float *__restrict__ v, long v_batch, long v_row,
+                                                      float *__restrict__ out, long o_batch, long o_row, int Lq,
+                                                      int Lk, float scale)
+{
+    __shared__ __attribute__((aligned(16))) float ks[TK][KP];
+    __shared__ __attribute__((aligned(16))) float vs[TK][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int hd = blockIdx.y, b = blockIdx.z;
+    const int qi = (blockIdx.x * WAVES + wave) * 32 + col;            // this lane's query
+    // B operand of the first product: Q[query][16*half .. +15], pre-scaled
+    float qv[16];
+    {
+        const float *qp = q + b * q_batch + (long)min(qi, Lq - 1) * q_row + hd * D + half * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4 *>(qp + c * 4);
+            qv[c * 4 + 0] = t.x * scale; qv[c * 4 + 1] = t.y * scale; qv[c * 4 + 2] = t.z * scale; qv[c * 4 + 3] = t.w * scale;
+        }
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;                                   // lsum: this lane half's part of the denominator
+    const float *kb = k + b * k_batch + hd * D, *vb = v + b * v_batch + hd * D;
+
+    for (int j0 = 0; j0 < Lk; j0 += TK) {
+        __syncthreads();                                               // everyone is done with the previous tile
+#pragma unroll
+        for (int u = 0; u < (TK * D / 4) / (64 * WAVES); ++u) {
+            const int e = tid + u * 64 * WAVES, r = e >> 3, c = e & 7;
+            const int j = min(j0 + r, Lk - 1);
+            *reinterpret_cast<float4 *>(&ks[r][c * 4]) = *reinterpret_cast<const float4 *>(kb + (long)j * k_row + c * 4);
+            *reinterpret_cast<float4 *>(&vs[r][c * 4]) = *reinterpret_cast<const float4 *>(vb + (long)j * v_row + c * 4);
+        }
+        __syncthreads();
+        // ---- S^T = K Q^T: A = K[key = col][16*half + t], B = qv[t] ----
+        float ka[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 t = *reinterpret_cast<const float4 *>(&ks[col][half * 16 + c * 4]);
+            ka[c * 4 + 0] = t.x; ka[c * 4 + 1] = t.y; ka[c * 4 + 2] = t.z; ka[c * 4 + 3] = t.w;
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qv[t], s, 0, 0, 0);
+        // ---- online softmax over this tile's keys, per query (= lanes l and l^32 together) ----
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= Lk) s[r] = -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float resc = __expf(m - mn);                             // 0 on the first tile
+        m = mn;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - mn);                                  // p; exp(-inf) = 0 for padded keys
+            psum += s[r];
+            o[r] *= resc;
+        }
+        lsum = lsum * resc + psum;
+        // ---- O^T += V^T P^T: MFMA r pairs key (r&3)+8(r>>2) (+4 for lane half 1) with p[r] ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float va = vs[(r & 3) + 8 * (r >> 2) + 4 * half][col];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s[r], o, 0, 0, 0);
+        }
+    }
+    const float l = lsum + __shfl_xor(lsum, 32);
+    if (qi < Lq) {
+        const float inv = 1.f / l;
+        float *op = out + b * o_batch + (long)qi * o_row + hd * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)                                    // registers 4g..4g+3 = channels 8g + 4*half + 0..3
+            *reinterpret_cast<float4 *>(op + 8 * g + 4 * half) =
+                make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" int dfx_mha_f32(const float *q, long q_batch, long q_row, const float *k, long k_batch, long k_row,
+                           const float *v, long v_batch, long v_row, float *out, long o_batch, long o_row, int B,
+                           int heads, int Lq, int Lk, float scale, void *stream)
+{
+    if (B < 0 || heads <= 0 || Lq < 0 || Lk < 0) return dfx::fail(DFX_EINVAL, "mha: bad dimension");
+    if ((long)B * Lq == 0) return DFX_OK;
+    if (!q || !k || !v || !out) return dfx::fail(DFX_EINVAL, "mha: null pointer");
+    if (Lk == 0) return dfx::fail(DFX_EINVAL, "mha: no keys (softmax over an empty set)");
+    if (((q_batch | q_row | k_batch | k_row | v_batch | v_row | o_batch | o_row) & 3) || !dfx::aligned16(q) ||
+        !dfx::aligned16(k) || !dfx::aligned16(v) || !dfx::aligned16(out))
+        return dfx::fail(DFX_EINVAL, "mha: strides must be multiples of 4 floats, buffers 16-byte aligned");
+    if (q_row < heads * D || k_row < heads * D || v_row < heads * D || o_row < heads * D)
+        return dfx::fail(DFX_EINVAL, "mha: row strides smaller than heads * 32");
+    if (B > 65535 || heads > 65535) return dfx::fail(DFX_ERANGE, "mha: grid too large");
+    const dim3 grid((unsigned)((Lq + 32 * WAVES - 1) / (32 * WAVES)), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(mha_fwd, grid, dim3(64 * WAVES), 0, static_cast<hipStream_t>(stream), q, q_batch, q_row, k,
+                       k_batch, k_row, v, v_batch, v_row, out, o_batch, o_row, Lq, Lk, scale);
+    return dfx::check_launch("mha_fwd");
+}

@@ -20,6 +20,8 @@ SIGNATURES = {
     "dfx_profile_drain": [_p, _p, _p, _p, _i],
     "dfx_msda_fused_level_fits": [_i, _i],
     "dfx_msda_fused_level_forward_f32": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    # include/dfx_mha.h: (ptr, batch stride, row stride) x (q, k, v, out), B, heads, Lq, Lk, scale, stream
+    "dfx_mha_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _i, ctypes.c_float, _p],
     # include/dfx_roi.h: input, rois, N, C, H, W, K, ph, pw, scale, sampling_ratio, aligned, out, stream
     "dfx_roi_align_nchw_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
     "dfx_roi_align_nhwc_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],

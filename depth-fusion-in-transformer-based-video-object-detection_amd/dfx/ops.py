@@ -338,6 +338,27 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     return out
 
 
+def mha(q, k, v, heads, scale):
+    """softmax(scale * q k^T) v per head (include/dfx_mha.h): q [B,Lq,E], k / v [B,Lk,E], E = 32*heads, fp32.
+    The tensors may be column slices of a joint projection (last dimension contiguous).  -> [B,Lq,E]"""
+    lib = _lib.load()
+    for nm, t in (("q", q), ("k", k), ("v", v)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{nm} must be a CUDA tensor (the fused attention has no CPU path)")
+        _require(t.dim() == 3 and t.dtype == torch.float32 and t.stride(2) == 1 and t.shape[2] == 32 * heads,
+                 f"mha: {nm} must be [B,L,32*heads] fp32 with a contiguous last dimension")
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    _require(k.shape == (B, Lk, E) and v.shape == (B, Lk, E), "mha: k and v must be [B,Lk,E]")
+    out = torch.empty((B, Lq, E), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.dfx_mha_f32(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                             v.data_ptr(), v.stride(0), v.stride(1), out.data_ptr(), Lq * E, E, B, heads, Lq, Lk,
+                             float(scale), _stream(q.device))
+    _lib.check(rc, "mha")
+    return out
+
+
 def box_refine(delta, reference, eps=1e-5):
     """sigmoid(delta + inverse_sigmoid(reference)) on the first reference.shape[-1] (2 or 4) of the 4 box
     columns, sigmoid(delta) on the others, in one launch (include/dfx_fused.h).  delta [...,4]."""

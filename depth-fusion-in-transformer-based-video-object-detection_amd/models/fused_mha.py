@@ -1,0 +1,45 @@
+"""nn.MultiheadAttention forward (eval, no masks) on the hand-written kernels: joint input projections
+on the MFMA GEMM, one fused attention launch (dfx_mha.h), output projection on the GEMM.
+
+The library path spends ~12 launches per call on 300 x 300 problems (projection pieces, scaling, two
+transposing copies, bmm, softmax, bmm, copy, projection); the 27 calls of a clip step are a fifth of its
+launches.  Arithmetic is the module's own: q = (x_q W_q^T + b_q) / sqrt(d), softmax(q k^T) v, out_proj.
+Inputs and output are batch-first [B, L, E] (the callers held batch-first tensors and transposed them
+only for the module).
+"""
+import math
+
+import torch
+
+from dfx import ops as _ops
+
+
+def usable(mha, *tensors):
+    """Inference on the GPU in fp32 with 32-wide heads and a packed in_proj: the fused route applies."""
+    return (not torch.is_grad_enabled() and mha.in_proj_weight is not None and mha.head_dim == 32
+            and mha.in_proj_bias is not None and not mha.batch_first and mha.bias_k is None and not mha.add_zero_attn
+            and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
+
+
+def forward(mha, q_in, k_in, v_in):
+    """mha: nn.MultiheadAttention; q_in [B,Lq,E], k_in / v_in [B,Lk,E] -> [B,Lq,E]
+    (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights)."""
+    E, H = mha.embed_dim, mha.num_heads
+    W, b = mha.in_proj_weight, mha.in_proj_bias
+    B, Lq, _ = q_in.shape
+    Lk = k_in.shape[1]
+    same_qk, same_kv = q_in is k_in, k_in is v_in
+    q_in, k_in, v_in = q_in.contiguous(), k_in.contiguous(), v_in.contiguous()
+    if same_qk and same_kv:                                 # one projection for q, k, v
+        qkv = _ops.linear(q_in, W, b).view(B, Lq, 3 * E)
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    elif same_qk:                                           # self-attention with positional q / k, plain v
+        qk = _ops.linear(q_in, W[:2 * E], b[:2 * E]).view(B, Lq, 2 * E)
+        q, k = qk[..., :E], qk[..., E:]
+        v = _ops.linear(v_in, W[2 * E:], b[2 * E:]).view(B, Lk, E)
+    else:
+        q = _ops.linear(q_in, W[:E], b[:E]).view(B, Lq, E)
+        k = _ops.linear(k_in, W[E:2 * E], b[E:2 * E]).view(B, Lk, E)
+        v = _ops.linear(v_in, W[2 * E:], b[2 * E:]).view(B, Lk, E)
+    ctx = _ops.mha(q, k, v, H, 1.0 / math.sqrt(E // H))
+    return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)

@@ -72,7 +72,13 @@ class RCNNHead(nn.Module):
         N, nr_boxes = pro_features.shape[:2]
         roi = roi_features.view(N * nr_boxes, self.d_model, -1).permute(2, 0, 1)          # 49,K,C
         q = pro_features.view(N, nr_boxes, self.d_model).permute(1, 0, 2)                 # nr,N,C
-        q = self.norm1(q + self.dropout1(self.self_attn(q, q, value=q)[0]))
+        from .. import fused_mha
+        if fused_mha.usable(self.self_attn, pro_features):
+            pf = pro_features.reshape(N, nr_boxes, self.d_model)
+            attn = fused_mha.forward(self.self_attn, pf, pf, pf).permute(1, 0, 2)           # nr,N,C
+        else:
+            attn = self.self_attn(q, q, value=q)[0]
+        q = self.norm1(q + self.dropout1(attn))
         q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
         obj = self.norm2(q + self.dropout2(self.inst_interact(q, roi)))
         y = self.linear2(self.dropout(self.activation(self.linear1(obj))))

@@ -37,6 +37,15 @@ def _add_pos(x, pos):
     return x if pos is None else x + pos
 
 
+def _mha(module, q, k, v):
+    """nn.MultiheadAttention on batch-first [B,L,E] tensors (no masks, attention weights unused): the fused
+    GEMM + attention-kernel route in GPU inference (models/fused_mha.py), the module itself otherwise."""
+    from . import fused_mha
+    if fused_mha.usable(module, q, k, v):
+        return fused_mha.forward(module, q, k, v)
+    return module(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1))[0].transpose(0, 1)
+
+
 def _norm_add(norm, x, y=None):
     """norm(x + y).  Inference on the GPU: one fused pass (dfx.ops.add_layernorm); otherwise the
     reference's two ops."""
@@ -291,7 +300,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        y = _mha(self.self_attn, qk, qk, tgt)
         tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
         y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
                             level_start_index, src_padding_mask)
@@ -390,11 +399,9 @@ class TemporalQueryEncoderLayer(nn.Module):
 
     def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
         qk = _add_pos(query, query_pos)
-        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), query.transpose(0, 1))[0].transpose(0, 1)
+        y = _mha(self.self_attn, qk, qk, query)
         tgt = _norm_add(self.norm2, query, self.dropout2(y))
-        y = self.cross_attn(_add_pos(tgt, query_pos).transpose(0, 1),
-                            _add_pos(ref_query, ref_query_pos).transpose(0, 1),
-                            ref_query.transpose(0, 1))[0].transpose(0, 1)
+        y = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query)
         tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
         return self.forward_ffn(tgt)
 
@@ -441,7 +448,7 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        y = self.self_attn(qk.transpose(0, 1), qk.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        y = _mha(self.self_attn, qk, qk, tgt)
         tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
         y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
                             frame_start_index, src_padding_mask)

@@ -122,3 +122,31 @@ def test_box_refine_matches_torch(rows, ref_dim):
     want = want.sigmoid()
     got = ops.box_refine(delta, ref)
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,Lq,Lk,mode", [(2, 300, 300, "self_pos"), (3, 300, 2480, "cross"), (4, 100, 100, "same"),
+                                          (1, 65, 33, "cross"), (2, 1, 1, "same"), (2, 64, 32, "self_pos"),
+                                          (1, 31, 95, "cross")])
+def test_fused_mha_matches_module(B, Lq, Lk, mode):
+    """models/fused_mha.py (GEMM projections + csrc/mha.hip) against nn.MultiheadAttention in eval mode."""
+    from models import fused_mha
+    torch.manual_seed(B * 1000 + Lq + Lk)
+    mod = torch.nn.MultiheadAttention(256, 8, dropout=0.1).cuda().eval()
+    with torch.no_grad():
+        mod.in_proj_bias.normal_(0, 0.2)
+        mod.out_proj.bias.normal_(0, 0.2)
+        x = torch.randn(B, Lq, 256, device="cuda") * 2
+        if mode == "same":
+            q = k = v = x
+        elif mode == "self_pos":
+            q = k = x + torch.randn(B, Lq, 256, device="cuda")
+            v = x
+        else:
+            q = x
+            k = torch.randn(B, Lk, 256, device="cuda") * 2
+            v = torch.randn(B, Lk, 256, device="cuda")
+        assert fused_mha.usable(mod, q, k, v)
+        want = mod(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1))[0].transpose(0, 1)
+        got = fused_mha.forward(mod, q, k, v)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-5), (got - want).abs().max().item()
