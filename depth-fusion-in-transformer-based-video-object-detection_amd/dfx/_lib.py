@@ -25,6 +25,7 @@ SIGNATURES = {
     # include/dfx_roi.h: input, rois, N, C, H, W, K, ph, pw, scale, sampling_ratio, aligned, out, stream
     "dfx_roi_align_nchw_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
     "dfx_roi_align_nhwc_f32": [_p, _p] + [_i] * 7 + [ctypes.c_float, _i, _i, _p, _p],
+    "dfx_dynamic_conv_f32": [_p, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_float, _p],
     # include/dfx_preprocess.h
     "dfx_preprocess_u8_f32": [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _p, _p],
     # include/dfx_gemm.h

@@ -338,6 +338,27 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     return out
 
 
+def dynamic_conv(feats, params, norm1, norm2):
+    """relu(norm2(relu(norm1(feats @ k1)) @ k2)) per RoI with k1, k2 cut from ``params`` (include/dfx_roi.h,
+    dfx_dynamic_conv_f32): feats [K,R,256] contiguous, params [K, 2*256*64] (rows may be strided), norm1 / norm2
+    nn.LayerNorm(64) / nn.LayerNorm(256).  -> [K,R,256]"""
+    lib = _lib.load()
+    _check_inputs([("feats", feats), ("norm1.weight", norm1.weight), ("norm2.weight", norm2.weight)])
+    K, R, C = feats.shape
+    dd = norm1.normalized_shape[0]
+    _require(params.is_cuda and params.dim() == 2 and params.shape[0] == K and params.stride(1) == 1
+             and params.shape[1] >= 2 * C * dd and params.dtype == torch.float32 and feats.dtype == torch.float32,
+             "dynamic_conv: params must be [K, 2*C*dd] fp32 with contiguous rows")
+    _require(norm2.normalized_shape[0] == C and norm1.eps == norm2.eps, "dynamic_conv: norm shapes / eps")
+    out = torch.empty_like(feats)
+    with torch.cuda.device(feats.device):
+        rc = lib.dfx_dynamic_conv_f32(feats.data_ptr(), params.data_ptr(), params.stride(0), norm1.weight.data_ptr(),
+                                      norm1.bias.data_ptr(), norm2.weight.data_ptr(), norm2.bias.data_ptr(),
+                                      out.data_ptr(), K, R, C, dd, float(norm1.eps), _stream(feats.device))
+    _lib.check(rc, "dynamic_conv")
+    return out
+
+
 def mha(q, k, v, heads, scale):
     """softmax(scale * q k^T) v per head (include/dfx_mha.h): q [B,Lq,E], k / v [B,Lk,E], E = 32*heads, fp32.
     The tensors may be column slices of a joint projection (last dimension contiguous).  -> [B,Lq,E]"""

@@ -39,6 +39,15 @@ class DynamicConv(nn.Module):
     def forward(self, pro_features, roi_features):
         """pro_features (1, K, C); roi_features (49, K, C) -> (K, C)."""
         feats = roi_features.permute(1, 0, 2)                               # K,49,C
+        if (feats.is_cuda and feats.dtype == torch.float32 and not torch.is_grad_enabled() and feats.is_contiguous()
+                and self.hidden_dim == 256 and self.dim_dynamic == 64 and feats.shape[1] <= 64
+                and isinstance(self.activation, nn.ReLU)):
+            # both per-RoI products and their LayerNorm + ReLU in one launch (csrc/dynconv.hip)
+            from dfx import ops as _ops
+            params2 = self.dynamic_layer(pro_features).view(feats.shape[0], -1)            # K, 2*C*dd
+            feats = _ops.dynamic_conv(feats, params2, self.norm1, self.norm2)
+            feats = self.out_layer(feats.flatten(1))
+            return self.activation(self.norm3(feats))
         params = self.dynamic_layer(pro_features).permute(1, 0, 2)          # K,1,2*C*dd
         k1 = params[:, :, : self.num_params].reshape(-1, self.hidden_dim, self.dim_dynamic)
         k2 = params[:, :, self.num_params:].reshape(-1, self.dim_dynamic, self.hidden_dim)

@@ -30,6 +30,18 @@ int dfx_roi_align_nhwc_f32(const float *input, const float *rois, int N, int C, 
                            int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
                            float *out, void *stream);
 
+/* DynamicConv of the query/RoI fusion head (Sparse R-CNN instance interaction) between the parameter
+ * Linear and the output Linear, one launch (/root/reference/models/sparse_roi_head/head.py:98-113):
+ *   k1 = params[r, 0 : C*dd] as [C,dd];  k2 = params[r, C*dd : 2*C*dd] as [dd,C]
+ *   y  = relu(LayerNorm_dd(feats[r] @ k1));   out[r] = relu(LayerNorm_C(y @ k2))
+ * for every RoI r: feats / out [K,R,C] (R = ph*pw <= 64 rows), params [K, >= 2*C*dd] with row stride
+ * p_stride (the dynamic_layer output as it stands), C = 256, dd = 64, eps 1e-5 inside the sqrt.
+ * The library runs this as two batched GEMMs of 49-row matrices plus four normalisation / ReLU passes
+ * over [K,R,C]; here each RoI's matrices stay in one CU's LDS between the two fp32-MFMA products. */
+int dfx_dynamic_conv_f32(const float *feats, const float *params, long p_stride,
+                         const float *g1, const float *b1, const float *g2, const float *b2,
+                         float *out, int K, int R, int C, int dd, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,7 @@ def _worker(rank, world, port, result_path):
     try:
         from models.clip_inference import ClipRunner
         torch.cuda.set_device(0)
+        torch.backends.cudnn.deterministic = True     # MIOpen's default solvers are not run-to-run deterministic
         model = _build()
         clip = _clip()
         per = clip.shape[0] // world
@@ -60,7 +61,12 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     mp.spawn(_worker, args=(2, port, result), nprocs=2, join=True)
     sharded = torch.load(result)
     from models.clip_inference import ClipRunner
-    whole = ClipRunner(_build(), micro_batch=2)(_clip().cuda())
+    saved = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        whole = ClipRunner(_build(), micro_batch=2)(_clip().cuda())
+    finally:
+        torch.backends.cudnn.deterministic = saved
     logits = torch.cat([s["pred_logits"] for s in sharded], 0)
     boxes = torch.cat([s["pred_boxes"] for s in sharded], 0)
     assert torch.allclose(logits, whole["pred_logits"].cpu(), atol=1e-5)

@@ -150,3 +150,24 @@ def test_fused_mha_matches_module(B, Lq, Lk, mode):
         got = fused_mha.forward(mod, q, k, v)
     assert got.shape == want.shape
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-5), (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("K,R", [(600, 49), (37, 49), (1, 49), (300, 64), (5, 7)])
+def test_dynamic_conv_matches_module(K, R):
+    """csrc/dynconv.hip against the reference formulation of DynamicConv (two bmm + LayerNorm + ReLU)."""
+    from dfx import ops
+    torch.manual_seed(K + R)
+    C, dd = 256, 64
+    feats = torch.randn(K, R, C, device="cuda")
+    params = torch.randn(K, 2 * C * dd, device="cuda") / 8
+    n1, n2 = torch.nn.LayerNorm(dd).cuda(), torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        for n in (n1, n2):
+            n.weight.normal_(1, 0.3)
+            n.bias.normal_(0, 0.3)
+        k1 = params[:, : C * dd].reshape(K, C, dd)
+        k2 = params[:, C * dd:].reshape(K, dd, C)
+        want = torch.relu(n2(torch.bmm(torch.relu(n1(torch.bmm(feats, k1))), k2)))
+        got = ops.dynamic_conv(feats, params, n1, n2)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=2e-4, atol=2e-4), (got - want).abs().max().item()
