@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void add_layernorm(const float *__restrict__ x
 }
 
 // stem epilogue: relu and +bias are monotonic, so relu(max(window) + b) == max(relu(window + b)).
-// One output row of one (image, channel) plane per workgroup pass; the 3 input rows it needs are read
-// through L1 (neighbouring outputs share 1-2 of their 3 columns).
+// One output row of one (image, channel) plane per workgroup pass; a thread makes 4 neighbouring outputs
+// from input columns 2*ox-1 .. 2*ox+7 of the 3 rows: per row one scalar and two 16-byte loads (rows of an
+// odd width are only 4-byte aligned, which global dwordx4 loads accept) instead of 9 scalar loads per output.
 __global__ __launch_bounds__(256) void bias_relu_maxpool(const float *__restrict__ x, const float *__restrict__ bias,
                                                          float *__restrict__ out, int C, int H, int W, int Ho, int Wo,
                                                          long rows)
@@ -107,20 +108,31 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool(const float *__restrict
         const float b = bias[plane % C];
         const float *src = x + plane * H * W;
         const int y0 = oy * 2 - 1;
-        for (int ox = threadIdx.x; ox < Wo; ox += blockDim.x) {
-            const int x0 = ox * 2 - 1;
-            float m = -INFINITY;
+        for (int ox = threadIdx.x * 4; ox < Wo; ox += blockDim.x * 4) {
+            const int xl = ox * 2 - 1;                       // leftmost input column (may be -1)
+            float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int yy = y0 + dy;
                 if (yy < 0 || yy >= H) continue;
+                const float *r = src + (long)yy * W;
+                float v[9];
+                v[0] = xl >= 0 ? r[xl] : -INFINITY;
+                if (xl + 8 < W) {                            // columns xl+1 .. xl+8 all inside the row
+                    const float4 p = *reinterpret_cast<const float4 *>(r + xl + 1);
+                    const float4 q = *reinterpret_cast<const float4 *>(r + xl + 5);
+                    v[1] = p.x; v[2] = p.y; v[3] = p.z; v[4] = p.w; v[5] = q.x; v[6] = q.y; v[7] = q.z; v[8] = q.w;
+                } else {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int xx = x0 + dx;
-                    if (xx >= 0 && xx < W) m = fmaxf(m, src[(long)yy * W + xx]);
+                    for (int k = 1; k < 9; ++k) v[k] = xl + k < W ? r[xl + k] : -INFINITY;
                 }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) m[o] = fmaxf(m[o], fmaxf(fmaxf(v[2 * o], v[2 * o + 1]), v[2 * o + 2]));
             }
-            out[row * Wo + ox] = fmaxf(m + b, 0.f);
+            float *dst = out + row * Wo + ox;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (ox + o < Wo) dst[o] = fmaxf(m[o] + b, 0.f);
         }
     }
 }
