@@ -278,5 +278,11 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     // operand reuse), and the 64 x 128 tile - 6 waves per SIMD - is the most even performer; the
     // 128 x 128 tile is kept for the large, deep convolutions of layer4 where it is 2-3 % ahead.
     if (M >= 1024 && (long)N * batch >= 16384 && K >= 512 && K <= 1024) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    // Few tiles (token GEMMs of a 4- or 8-frame rank block): all workgroups are resident at once, the CUs that get
+    // one tile more than the others set the time.  A 64 x 64 tile halves that quantum (M = 16800, N = 256:
+    // 526 tiles of 64 x 128 = 3 on some CUs, 2.05 on average; 1052 of 64 x 64 = 5 against 4.1).
+    auto fill = [](long tiles) { return (double)tiles / (256.0 * (double)((tiles + 255) / 256)); };
+    const long t128 = (long)((M + 63) / 64) * ((N + 127) / 128) * batch, t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    if (t128 < 8 * 256 && 0.95 * fill(t64) > fill(t128)) return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }
