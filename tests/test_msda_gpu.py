@@ -107,7 +107,7 @@ def test_backward_matches_oracle(msda, oracle, geom):
         assert torch.allclose(g.cpu().double(), r, **tol)
 
 
-@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025])
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025, 2048, 3096])   # the reference's own list (models/ops/test.py:81-86)
 def test_gradcheck_like_reference(msda, channels):
     """models/ops/test.py:63-86: analytic gradient of the op vs numerical, in double."""
     from models.ops.functions import MSDeformAttnFunction
