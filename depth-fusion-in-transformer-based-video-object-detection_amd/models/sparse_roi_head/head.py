@@ -90,5 +90,10 @@ class RCNNHead(nn.Module):
         q = self.norm1(q + self.dropout1(attn))
         q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
         obj = self.norm2(q + self.dropout2(self.inst_interact(q, roi)))
-        y = self.linear2(self.dropout(self.activation(self.linear1(obj))))
+        if (self.activation is F.relu and obj.is_cuda and obj.dtype == torch.float32 and not torch.is_grad_enabled()):
+            from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue
+            hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
+        else:
+            hdn = self.activation(self.linear1(obj))
+        y = self.linear2(self.dropout(hdn))
         return self.norm3(obj + self.dropout3(y))

@@ -37,6 +37,16 @@ def _add_pos(x, pos):
     return x if pos is None else x + pos
 
 
+def _linear_act(linear, activation, x):
+    """activation(linear(x)); in GPU inference with ReLU the bias and the ReLU ride in the GEMM epilogue
+    (one launch instead of two per FFN of the 300-query layers)."""
+    if (activation is F.relu and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and linear.in_features % 4 == 0):
+        from dfx import ops as _ops
+        return _ops.linear(x.contiguous(), linear.weight, linear.bias, relu=True)
+    return activation(linear(x))
+
+
 def _mha(module, q, k, v):
     """nn.MultiheadAttention on batch-first [B,L,E] tensors (no masks, attention weights unused): the fused
     GEMM + attention-kernel route in GPU inference (models/fused_mha.py), the module itself otherwise."""
@@ -294,7 +304,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
         return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
@@ -394,7 +404,7 @@ class TemporalQueryEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
         return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
@@ -442,7 +452,7 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
         return _norm_add(self.norm3, tgt, self.dropout4(y))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
