@@ -23,7 +23,9 @@ The JSON line also carries
                single-stream step after it and both averages are reported.
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
-               (one 12-frame clip at full resolution, ~12 s) on the box's host cores.
+               (one 12-frame clip at full resolution, ~12 s) on the box's host cores; the same clip then
+               goes through the HIP path and the differences are reported (`check_vs_hip_path`: the
+               oracle as checker at 800x1333, where the unit tests use small images).
 """
 import argparse
 import json
@@ -88,13 +90,21 @@ def cpu_baseline(height, width, threads, frames=12):
         clip = torch.randn(frames, 4, height, width, generator=torch.Generator().manual_seed(42))
         runner = ClipRunner(model, micro_batch=1)
         t0 = time.perf_counter()
-        runner(clip)
+        want = runner(clip)
         dt = time.perf_counter() - t0
     finally:
         f.MSDeformAttnFunction, ops.roi_align = saved
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    line = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"one {frames}-frame clip at {height}x{width}, all-current mode, {dt:.1f} s of CPU work, "
                       "torch CPU ops + oracle/msda_oracle.c for MSDA and RoIAlign"}
+    # the same clip through the HIP path (same seed -> same weights): the checker role of the oracle, at full resolution
+    got = ClipRunner(build(torch.device("cuda", torch.cuda.current_device()), frames - 1), micro_batch=frames)(clip.cuda())
+    line["check_vs_hip_path"] = {
+        "max_abs_diff_pred_logits": float((got["pred_logits"].cpu() - want["pred_logits"]).abs().max()),
+        "max_abs_diff_pred_boxes": float((got["pred_boxes"].cpu() - want["pred_boxes"]).abs().max()),
+        "temporal_topk_sets_equal": all(set(a.tolist()) == set(b.tolist())
+                                        for pg, pc in zip(got["topk"], want["topk"]) for a, b in zip(pg.cpu(), pc))}
+    return line
 
 
 def main():
