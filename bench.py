@@ -123,10 +123,11 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="two-stream schedule inside a rank: backbones of micro-batch i+1 beside the transformer "
                          "tail of micro-batch i (ClipRunner; same results)")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="clips are a stream: queue each step with ClipRunner.submit, so the transformer tail of clip k "
                          "runs on a second HIP stream beside the backbones of clip k+1 (same results; 0 = one clip at a "
-                         "time on one stream; 1 = on for a single GPU; 2 = on for N > 1 as well)")
+                         "time on one stream - the default, so that the MSDA kernel's stamped times in the timed region are "
+                         "its own; 1 = on for a single GPU: +3-4 %% frames/s; 2 = on for N > 1 as well)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="ask MIOpen for run-to-run deterministic convolution solvers (costs ~6 %% here)")
     ap.add_argument("--backend", default="nccl",
