@@ -82,3 +82,35 @@ def test_real_model_state_dict_round_trip(tmp_path):
     assert missing == [] and unexpected == []
     for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_memo_on_tensor_identity_and_version():
+    """util/memo.py: a value derived from a (mask) tensor is rebuilt when the tensor object or its version
+    counter changes, shared otherwise, and never cached while autograd records."""
+    import torch
+    from util import memo
+    memo.clear()
+    calls = []
+
+    def build(t):
+        calls.append(1)
+        return (~t).cumsum(1, dtype=torch.float32)
+
+    m = torch.zeros(2, 5, dtype=torch.bool)
+    with torch.no_grad():
+        a = memo.memo_on(m, "x", lambda: build(m))
+        b = memo.memo_on(m, "x", lambda: build(m))
+        assert a is b and len(calls) == 1
+        assert memo.memo_on(m, "y", lambda: build(m)) is not a and len(calls) == 2      # another tag
+        m[0, 0] = True                                                                     # in-place edit: version bump
+        c = memo.memo_on(m, "x", lambda: build(m))
+        assert c is not a and len(calls) == 3 and c[0, 0] == 0
+        m2 = m.clone()                                                                     # equal content, another object
+        assert memo.memo_on(m2, "x", lambda: build(m2)) is not c and len(calls) == 4
+        view = m[:1]
+        view[0, 1] = True                                                                  # edit through a view bumps the base
+        assert memo.memo_on(m, "x", lambda: build(m)) is not c and len(calls) == 5
+    with torch.enable_grad():
+        memo.memo_on(m, "x", lambda: build(m))
+        assert len(calls) == 6                                                             # no caching under autograd
+    memo.clear()
