@@ -75,6 +75,11 @@ class DFormerBackbone(nn.Module):
         assert m is not None, "Input mask is None."
         out: Dict[str, NestedTensor] = {}
         stages = self.depth_backbone.downsample_layers_e[:-1]        # the 4th stage is never run
+        if (not self.return_interm_layers and x.is_cuda and not torch.is_grad_enabled()
+                and not any(mod.training for mod in stages.modules() if isinstance(mod, nn.BatchNorm2d))):
+            x = self._forward_folded(stages, x)
+            out["0"] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))
+            return out
         for i, stage in enumerate(stages):
             x = stage(x)
             if self.return_interm_layers:
@@ -82,6 +87,41 @@ class DFormerBackbone(nn.Module):
         if not self.return_interm_layers:
             out["0"] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))
         return out
+
+    def _forward_folded(self, stages, x):
+        """Inference with every BatchNorm (eval mode: running statistics) folded into the convolution BEFORE it:
+        conv -> BN [-> BN of the next stage] is one convolution with scaled weights and a new bias, so the four
+        normalisation passes over the full-resolution depth maps disappear.  A stage's leading BN follows the
+        previous stage's last operation directly (only the last stage's output is returned here), and the zero
+        padding of the next convolution is applied after it in both formulations, so the result is the same
+        up to rounding."""
+        key = tuple((t.data_ptr(), t._version) for mod in stages.modules() if isinstance(mod, (nn.Conv2d, nn.BatchNorm2d))
+                    for t in list(mod.parameters(recurse=False)) + list(mod.buffers(recurse=False)))
+        if getattr(self, "_folded", None) is None or self._folded[0] != key:
+            ops = [mod for stage in stages for mod in stage]       # conv, bn, gelu, conv, bn | bn, conv | bn, conv
+            plan = []                                              # (weight, bias, stride, padding, gelu_after)
+            i = 0
+            while i < len(ops):
+                conv = ops[i]
+                assert isinstance(conv, nn.Conv2d), "DownsamplePath starts every affine chain with a convolution"
+                w = conv.weight.detach().clone()
+                b = conv.bias.detach().clone() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+                i += 1
+                while i < len(ops) and isinstance(ops[i], nn.BatchNorm2d):
+                    bn = ops[i]
+                    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+                    w = w * scale.view(-1, 1, 1, 1)
+                    b = (b - bn.running_mean) * scale + bn.bias.detach()
+                    i += 1
+                gelu = i < len(ops) and isinstance(ops[i], nn.GELU)
+                i += int(gelu)
+                plan.append((w.contiguous(), b.contiguous(), conv.stride, conv.padding, gelu))
+            self._folded = (key, plan)
+        for w, b, stride, padding, gelu in self._folded[1]:
+            x = F.conv2d(x, w, b, stride, padding)
+            if gelu:
+                x = F.gelu(x)
+        return x
 
     def load_pretrained_weights(self, model, pretrained_weights_path, prefix="downsample_layers_e"):
         """Partial load of a DFormer checkpoint ({'state_dict': ...}): conv / BN affine tensors whose
