@@ -1,0 +1,324 @@
+// 3x3 stride-1 convolution by Winograd F(2x2, 3x3) in ONE kernel on the gfx950 matrix cores
+// (include/dfx_conv.h, dfx_conv3x3_wino_f32): the 3x3 convolutions of ResNet-50's bottlenecks, dilated DC5
+// stage included (/root/reference/models/backbone_scratch.py:102-141,156-159 -> torchvision Bottleneck.conv2).
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+//
+// The element-wise product summed over ci is, for each of the 16 positions of the 4x4 transform domain, a GEMM
+//   M_pos[Co, tiles] = U_pos[Co, Ci] x V_pos[Ci, tiles]
+// and those 16 GEMMs run on v_mfma_f32_32x32x2_f32 (exact fp32): 2.25x fewer multiplications than the direct
+// form, the transforms are additions.  Nothing transformed ever reaches HBM:
+//
+//   workgroup = 512 threads = 8 waves, output block = 64 output channels x 64 tiles (tiles are numbered
+//   through the whole batch, so only the last workgroup has idle lanes); wave w owns transform positions
+//   2w and 2w+1 for the whole block: 2 x (2 x 2) MFMA tiles = 128 accumulator registers.
+//   K loop over input channels in chunks of 8, double-buffered LDS stage, one barrier per chunk:
+//     U chunk  [16 pos][2][64 co][4 ci]  32 KB, contiguous in the pre-blocked weight tensor (16-byte loads,
+//              ds_write_b128; a lane's ds_read_b128 = its A operand of the chunk's four MFMAs)
+//     V chunk  [16 pos][8 ci][64 tiles]  32 KB: thread (ci = wave, tile = lane) loads its 4x4 input patch
+//              straight from the NCHW map (clamped addresses, out-of-map taps zeroed by select), applies
+//              B^T d B in registers (32 additions) and stores 16 dwords; B operands by ds_read_b32
+//     the next chunk's loads are issued before the current chunk's 32 MFMAs, transformed and stored after.
+//   Epilogue: the accumulators of the 8 waves meet in LDS ([16 pos][16 co][64 tiles] per pass, 4 passes,
+//   alternating halves of the stage memory), thread (co, tile) gathers its 16 values, applies A^T M A,
+//   bias, activation, and writes the 2x2 outputs.
+//   Dilation d: the same arithmetic on the d x d interleaved sub-lattices - a tile's outputs are
+//   (y0, y0+d) x (x0, x0+d), its taps (y0 + (i-1)d, x0 + (j-1)d).
+// MFMA-bound: 2*16*Co*Ci flops per tile against 157 TFLOP/s = 2.25x the direct form's rate at equal speed.
+#include "dfx_common.h"
+#include "dfx_conv.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WinoArgs {
+    const float *X, *U, *bias;
+    float *Y;
+    int Ci, H, W, Co, dil, act;
+    int TY, TX;          // tiles per image column / row
+    long tiles;          // N * TY * TX
+    long strideX, strideY;
+    int nchunk, ntb;     // Ci / 8, tile blocks
+    unsigned xbytes, ubytes;
+};
+
+__device__ __forceinline__ float activate(float v, int act)
+{
+    if (act == DFX_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DFX_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+constexpr int kCoB = 64, kTB = 64, kCK = 8;
+constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk (8192)
+constexpr int kVChunk = 16 * kCK * kTB;           // floats per V chunk (8192)
+
+__global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * (kUChunk + kVChunk)];      // 128 KB
+    float *const Us = smem;                       // [2][kUChunk]
+    float *const Vs = smem + 2 * kUChunk;         // [2][kVChunk]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, c = lane & 31;
+
+    // XCD-aware decode: logical block = co block (slow) x tile block (fast); each XCD walks one contiguous range,
+    // so the U slice of a co block stays in that XCD's L2
+    const int lb = dfx::xcd_remap(blockIdx.x, gridDim.x);
+    const int cob = lb / g.ntb, tb = lb - cob * g.ntb;
+    const int co0 = cob * kCoB;
+
+    // this thread's tile (the same tile for the input patch it loads and the outputs it writes)
+    const long t = (long)tb * kTB + lane;
+    const bool tv = t < g.tiles;
+    const long tc = tv ? t : 0;
+    const int per_img = g.TY * g.TX;
+    const int n = (int)(tc / per_img);
+    const int rem = (int)(tc - (long)n * per_img);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    const int d = g.dil;
+    const int y0 = (ty / d) * 2 * d + ty % d, x0 = (tx / d) * 2 * d + tx % d;
+
+    // input patch: clamped row / column offsets + validity bits
+    int roff[4], coff[4];
+    unsigned okbits = 0;      // bit i: row i valid, bit 4+j: column j valid
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = y0 + (i - 1) * d, xx = x0 + (i - 1) * d;
+        if (tv && (unsigned)yy < (unsigned)g.H) okbits |= 1u << i;
+        if (tv && (unsigned)xx < (unsigned)g.W) okbits |= 1u << (4 + i);
+        roff[i] = min(max(yy, 0), g.H - 1) * g.W;
+        coff[i] = min(max(xx, 0), g.W - 1);
+    }
+    const int HW = g.H * g.W;
+    // buffer loads: wave-uniform descriptor (base, size) + per-lane 32-bit byte offset + scalar chunk offset
+    // (checked on the host: the whole input < 2^32 bytes); 16 offset registers, no 64-bit address arithmetic
+    unsigned xoff[16];
+    {
+        const unsigned b = (unsigned)((long)n * g.strideX) + (unsigned)(wave * HW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xoff[i * 4 + j] = (b + (unsigned)(roff[i] + coff[j])) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.X), 0, (int)g.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.U), 0, (int)g.ubytes, 0x00020000);
+    const unsigned ubase = (unsigned)cob * g.nchunk * (kUChunk * 4u);
+
+    f32x16 acc[2][2][2];      // [position][co tile][tile tile]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
+
+    float xr[16];
+    f32x4 ur[4];
+    auto load_chunk = [&](int ch) {
+        const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offsets
+        const unsigned us = ubase + (unsigned)ch * (kUChunk * 4u);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[i], xs, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, (unsigned)(tid * 16 + i * 8192), us, 0));
+    };
+    auto store_chunk = [&](int buf) {
+        float *us = Us + buf * kUChunk + tid * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(us + i * 2048) = ur[i];
+        // B^T d B
+        float dd[16], tm[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dd[i * 4 + j] = ((okbits >> i) & (okbits >> (4 + j)) & 1u) ? xr[i * 4 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tm[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
+            tm[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
+            tm[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
+            tm[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
+        }
+        float *vs = Vs + buf * kVChunk + wave * kTB + lane;       // [pos][ci = wave][tile = lane]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vs[(i * 4 + 0) * (kCK * kTB)] = tm[i * 4 + 0] - tm[i * 4 + 2];
+            vs[(i * 4 + 1) * (kCK * kTB)] = tm[i * 4 + 1] + tm[i * 4 + 2];
+            vs[(i * 4 + 2) * (kCK * kTB)] = tm[i * 4 + 2] - tm[i * 4 + 1];
+            vs[(i * 4 + 3) * (kCK * kTB)] = tm[i * 4 + 1] - tm[i * 4 + 3];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch < g.nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < g.nchunk) load_chunk(ch + 1);       // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        // operand fragments of both positions up front: the second position's LDS reads complete under the
+        // first position's MFMAs
+        f32x4 af[2][2];
+        float bf[2][4][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int pos = wave * 2 + p;
+            const float *ub = Us + buf * kUChunk + (pos * 2 + half) * (kCoB * 4) + c * 4;
+            const float *vb = Vs + buf * kVChunk + (pos * kCK + half * 4) * kTB + c;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const f32x4 *>(ub + i * 32 * 4);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[p][tt][j] = vb[tt * kTB + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float av = af[p][i][tt];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[p][tt][j], acc[p][i][j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < g.nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: meet in LDS, A^T M A, bias, activation ----
+    // pass q takes accumulator registers 4q..4q+3 of every MFMA tile: local co rows i*32 + 8q + 4*half + rr,
+    // compacted to cl = i*8 + 4*half + rr
+    float *Y = g.Y + (long)n * g.strideY;
+    const int P = HW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float *ms = smem + (q & 1) * (16 * 16 * kTB);            // [16 pos][16 cl][64 tiles]
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        ms[((wave * 2 + p) * 16 + i * 8 + 4 * half + rr) * kTB + j * 32 + c] = acc[p][i][j][4 * q + rr];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cl = wave + 8 * s;
+            const int co = co0 + (cl >> 3) * 32 + 8 * q + (cl & 7);
+            float m[16];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) m[pos] = ms[(pos * 16 + cl) * kTB + lane];
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+            }
+            const float bv = g.bias ? g.bias[co] : 0.f;
+            const float y00 = activate(t0[0] + t0[1] + t0[2] + bv, g.act), y01 = activate(t0[1] - t0[2] - t0[3] + bv, g.act);
+            const float y10 = activate(t1[0] + t1[1] + t1[2] + bv, g.act), y11 = activate(t1[1] - t1[2] - t1[3] + bv, g.act);
+            if (tv && y0 < g.H && x0 < g.W) {        // (a dilated map's last tile row / column can lie outside it)
+                float *yp = Y + (long)co * P + y0 * g.W + x0;
+                const bool xv = x0 + d < g.W, yv = y0 + d < g.H;
+                yp[0] = y00;
+                if (xv) yp[d] = y01;
+                if (yv) {
+                    yp[d * g.W] = y10;
+                    if (xv) yp[d * g.W + d] = y11;
+                }
+            }
+        }
+    }
+}
+
+// w [Co][Ci][3][3] -> U = G g G^T in the blocked order the kernel stages: [Co/64][Ci/8][16 pos][2][64 co][4 ci]
+__global__ void wino_weights_kernel(const float *w, const float *scale, float *u, int Co, int Ci)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Co * Ci) return;
+    const int co = idx / Ci, ci = idx - co * Ci;
+    const float s = scale ? scale[co] : 1.f;
+    float gk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gk[i] = w[(long)idx * 9 + i] * s;
+    // G g : 4x3
+    float t[12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t[0 * 3 + j] = gk[0 * 3 + j];
+        t[1 * 3 + j] = 0.5f * (gk[0 * 3 + j] + gk[1 * 3 + j] + gk[2 * 3 + j]);
+        t[2 * 3 + j] = 0.5f * (gk[0 * 3 + j] - gk[1 * 3 + j] + gk[2 * 3 + j]);
+        t[3 * 3 + j] = gk[2 * 3 + j];
+    }
+    float uu[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uu[i * 4 + 0] = t[i * 3 + 0];
+        uu[i * 4 + 1] = 0.5f * (t[i * 3 + 0] + t[i * 3 + 1] + t[i * 3 + 2]);
+        uu[i * 4 + 2] = 0.5f * (t[i * 3 + 0] - t[i * 3 + 1] + t[i * 3 + 2]);
+        uu[i * 4 + 3] = t[i * 3 + 2];
+    }
+    const int cob = co / kCoB, col = co % kCoB, chunk = ci / kCK, kq = (ci % kCK) / 4, e = ci % 4;
+    const long base = ((long)cob * (Ci / kCK) + chunk) * kUChunk;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) u[base + ((pos * 2 + kq) * kCoB + col) * 4 + e] = uu[pos];
+}
+
+}  // namespace
+
+extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float *bias, float *y, int N, int Ci, int H,
+                                    int W, int Co, int dilation, int act, void *stream)
+{
+    if (N < 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || dilation <= 0)
+        return dfx::fail(DFX_EINVAL, "conv3x3_wino: bad dimension");
+    if (N == 0) return DFX_OK;
+    if (!x || !u || !y) return dfx::fail(DFX_EINVAL, "conv3x3_wino: null pointer");
+    if (Ci % kCK || Co % kCoB) return dfx::fail(DFX_EINVAL, "conv3x3_wino: Ci must be a multiple of 8, Co of 64");
+    if (!dfx::aligned16(u)) return dfx::fail(DFX_EINVAL, "conv3x3_wino: u must be 16-byte aligned");
+    if ((long)N * Ci * H * W >= (1L << 30) || (long)Co * H * W >= (1L << 31))
+        return dfx::fail(DFX_ERANGE, "conv3x3_wino: input exceeds 2^30 elements (split the batch)");
+    if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "conv3x3_wino: unknown activation");
+    WinoArgs g{};
+    g.X = x; g.U = u; g.bias = bias; g.Y = y;
+    g.Ci = Ci; g.H = H; g.W = W; g.Co = Co; g.dil = dilation; g.act = act;
+    g.TY = (H + 2 * dilation - 1) / (2 * dilation) * dilation;
+    g.TX = (W + 2 * dilation - 1) / (2 * dilation) * dilation;
+    g.tiles = (long)N * g.TY * g.TX;
+    g.strideX = (long)Ci * H * W;
+    g.strideY = (long)Co * H * W;
+    g.nchunk = Ci / kCK;
+    g.xbytes = (unsigned)((long)N * Ci * H * W * 4);
+    g.ubytes = (unsigned)((long)16 * Co * Ci * 4);
+    const long ntb = (g.tiles + kTB - 1) / kTB;
+    const long blocks = ntb * (Co / kCoB);
+    if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "conv3x3_wino: grid too large");
+    g.ntb = (int)ntb;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(512), 0, static_cast<hipStream_t>(stream), g);
+    return dfx::check_launch("conv_wino_kernel");
+}
+
+extern "C" int dfx_wino_weights_f32(const float *w, const float *scale, float *u, int Co, int Ci, void *stream)
+{
+    if (Co <= 0 || Ci <= 0 || Ci % kCK || Co % kCoB)
+        return dfx::fail(DFX_EINVAL, "wino_weights: Ci must be a multiple of 8, Co of 64");
+    if (!w || !u) return dfx::fail(DFX_EINVAL, "wino_weights: null pointer");
+    const int total = Co * Ci;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       scale, u, Co, Ci);
+    return dfx::check_launch("wino_weights_kernel");
+}

@@ -35,6 +35,10 @@ SIGNATURES = {
     "dfx_bias_relu_maxpool_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "dfx_add_layernorm_f32": [_p, _p, _p, _p, _p, _l, _i, ctypes.c_float, _p],
     "dfx_box_refine_f32": [_p, _p, _i, _p, _l, ctypes.c_float, _p],
+    # include/dfx_conv.h
+    "dfx_conv2d_igemm_f32": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
+    "dfx_conv3x3_wino_f32": [_p, _p, _p, _p] + [_i] * 7 + [_p],
+    "dfx_wino_weights_f32": [_p, _p, _p, _i, _i, _p],
 }
 
 

@@ -431,3 +431,67 @@ def bias_relu_maxpool(x, bias):
         rc = lib.dfx_bias_relu_maxpool_f32(x.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, H, W, _stream(x.device))
     _lib.check(rc, "bias_relu_maxpool")
     return out
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+
+
+class ConvPlan:
+    """One convolution prepared for the hand-written kernels (include/dfx_conv.h): 3x3 / stride 1 / "same"
+    convolutions with Ci % 8 == 0 and Co % 64 == 0 run as fused Winograd F(2x2, 3x3) (weights pre-transformed
+    on the GPU by dfx_wino_weights_f32), everything else as an implicit GEMM over a tap table (weights
+    re-ordered [Co, (ky, kx, ci)], K padded to a multiple of 16).  ``scale`` (per output channel, e.g. the
+    folded FrozenBatchNorm2d factor) is multiplied into the weights; ``bias`` and ``act`` run in the epilogue."""
+
+    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, act=None, scale=None, algo=None):
+        _require(weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4, "ConvPlan: fp32 CUDA weight [Co,Ci,kh,kw]")
+        stride, padding, dilation = (v[0] if isinstance(v, (tuple, list)) else v for v in (stride, padding, dilation))
+        Co, Ci, kh, kw = weight.shape
+        self.Co, self.Ci, self.kh, self.kw = Co, Ci, kh, kw
+        self.stride, self.padding, self.dilation, self.act = int(stride), int(padding), int(dilation), ACT[act]
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        wino_ok = kh == 3 and kw == 3 and stride == 1 and padding == dilation and Ci % 8 == 0 and Co % 64 == 0
+        self.algo = algo or ("wino" if wino_ok else "igemm")
+        _require(self.algo != "wino" or wino_ok, "ConvPlan: geometry not covered by the Winograd kernel")
+        w = weight.detach().contiguous()
+        lib = _lib.load()
+        if self.algo == "wino":
+            self.u = torch.empty(16 * Co * Ci, dtype=torch.float32, device=w.device)
+            sc = None if scale is None else scale.detach().float().contiguous()
+            with torch.cuda.device(w.device):
+                rc = lib.dfx_wino_weights_f32(w.data_ptr(), _ptr(sc), self.u.data_ptr(), Co, Ci, _stream(w.device))
+            _lib.check(rc, "wino_weights")
+        else:
+            if scale is not None:
+                w = w * scale.detach().reshape(-1, 1, 1, 1)
+            K = kh * kw * Ci
+            Kpad = (K + 15) // 16 * 16
+            _require(Ci < 65536 and (kh - 1) * dilation < 256 and (kw - 1) * dilation < 128, "ConvPlan: tap table range")
+            wp = torch.zeros(Co, Kpad, dtype=torch.float32, device=w.device)
+            wp[:, :K] = w.permute(0, 2, 3, 1).reshape(Co, K)
+            ky, kx, ci = torch.meshgrid(torch.arange(kh), torch.arange(kw), torch.arange(Ci), indexing="ij")
+            tab = torch.full((Kpad,), -1, dtype=torch.int32)
+            tab[:K] = (ci | ((ky * dilation) << 16) | ((kx * dilation) << 24)).reshape(-1).to(torch.int32)
+            self.wp, self.ktab, self.Kpad = wp, tab.to(w.device), Kpad
+
+    def out_size(self, H, W):
+        eff_h, eff_w = (self.kh - 1) * self.dilation + 1, (self.kw - 1) * self.dilation + 1
+        return (H + 2 * self.padding - eff_h) // self.stride + 1, (W + 2 * self.padding - eff_w) // self.stride + 1
+
+    def __call__(self, x):
+        lib = _lib.load()
+        _check_inputs([("x", x)])
+        _require(x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.Ci, "conv: x must be [N,Ci,H,W] fp32")
+        N, _, H, W = x.shape
+        Ho, Wo = self.out_size(H, W)
+        y = torch.empty((N, self.Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            if self.algo == "wino":
+                rc = lib.dfx_conv3x3_wino_f32(x.data_ptr(), self.u.data_ptr(), _ptr(self.bias), y.data_ptr(), N, self.Ci,
+                                              H, W, self.Co, self.dilation, self.act, _stream(x.device))
+            else:
+                rc = lib.dfx_conv2d_igemm_f32(x.data_ptr(), self.wp.data_ptr(), self.ktab.data_ptr(), _ptr(self.bias),
+                                              y.data_ptr(), N, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad, self.stride,
+                                              self.padding, self.act, _stream(x.device))
+        _lib.check(rc, "conv " + self.algo)
+        return y

@@ -1,0 +1,96 @@
+"""GPU: the hand-written convolutions (csrc/conv_igemm.hip, csrc/conv_wino.hip) against float64 conv2d.
+The products run on exact-fp32 MFMA; Winograd F(2x2,3x3) adds the rounding of its transforms (inputs
+up to 4x, filters exact halves/quarters), so its bound is a few times the direct form's."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, stride, pad, dil, act):
+    y = F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride, pad, dil)
+    if act == "relu":
+        y = y.relu()
+    elif act == "gelu":
+        y = F.gelu(y)
+    return y
+
+
+CASES = [  # N, Ci, Co, H, W, k, stride, pad, dil, act
+    (2, 3, 64, 67, 90, 7, 2, 3, 1, None),          # ResNet stem geometry
+    (2, 64, 64, 25, 41, 3, 1, 1, 1, "relu"),       # layer1 conv2
+    (2, 128, 128, 27, 35, 3, 2, 1, 1, "relu"),     # layer2.0 conv2 (stride 2, odd map)
+    (1, 256, 256, 20, 34, 3, 2, 1, 1, "relu"),     # layer3.0 conv2
+    (2, 64, 128, 13, 21, 3, 1, 2, 2, "relu"),      # dilated
+    (3, 1, 16, 40, 67, 3, 2, 1, 1, "gelu"),        # DFormer stem, first convolution
+    (2, 16, 32, 20, 34, 3, 2, 1, 1, None),
+    (2, 32, 64, 21, 33, 3, 2, 1, 1, None),
+    (1, 24, 40, 9, 11, 5, 1, 2, 1, "relu"),        # odd everything
+    (1, 8, 200, 6, 7, 1, 1, 0, 1, None),           # 1x1, Co not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,k,stride,pad,dil,act", CASES)
+def test_igemm_matches_fp64(N, Ci, Co, H, W, k, stride, pad, dil, act):
+    from dfx import ops
+    g = torch.Generator().manual_seed(Ci * 131 + Co + H)
+    x = torch.randn(N, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    plan = ops.ConvPlan(w, b, stride, pad, dil, act, algo="igemm")
+    got = plan(x)
+    want = _ref(x, w, b, stride, pad, dil, act)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
+
+
+WINO = [  # N, Ci, Co, H, W, dil
+    (2, 64, 64, 24, 40, 1),
+    (3, 64, 64, 25, 41, 1),        # odd map: edge tiles with one valid row / column
+    (1, 128, 128, 50, 84, 1),
+    (2, 256, 256, 13, 21, 1),
+    (2, 512, 512, 13, 21, 2),      # DC5 stage
+    (1, 64, 128, 50, 84, 2),
+    (5, 8, 64, 7, 5, 1),           # tiles of several images inside one workgroup
+    (2, 16, 64, 9, 10, 3),
+]
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,dil", WINO)
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_winograd_matches_fp64(N, Ci, Co, H, W, dil, act):
+    from dfx import ops
+    g = torch.Generator().manual_seed(Ci * 7 + Co + H + dil)
+    x = torch.randn(N, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    scale = (torch.rand(Co, generator=g) + 0.5).cuda()
+    plan = ops.ConvPlan(w, b, 1, dil, dil, act, scale=scale)
+    assert plan.algo == "wino"
+    got = plan(x)
+    want = _ref(x, w * scale.view(-1, 1, 1, 1), b, 1, dil, dil, act)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 1.5e-5 * (Ci * 9) ** 0.5 / 3
+
+
+def test_winograd_equals_igemm_closely_on_inf_free_borders():
+    """The two algorithms on one problem (validity masks of edge tiles, dilation phases)."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 50, 84, generator=g).cuda()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
+    for dil in (1, 2):
+        a = ops.ConvPlan(w, None, 1, dil, dil, None, algo="wino")(x)
+        b = ops.ConvPlan(w, None, 1, dil, dil, None, algo="igemm")(x)
+        assert (a - b).abs().max().item() < 2e-5
+
+
+def test_conv_plan_rejects_cpu_and_bad_geometry():
+    from dfx import ops
+    with pytest.raises(RuntimeError):
+        ops.ConvPlan(torch.randn(64, 64, 3, 3), None, 1, 1, 1)
+    w = torch.randn(64, 60, 3, 3).cuda()
+    assert ops.ConvPlan(w, None, 1, 1, 1).algo == "igemm"       # Ci % 8 != 0 -> implicit GEMM
+    with pytest.raises(RuntimeError):
+        ops.ConvPlan(w, None, 1, 1, 1, algo="wino")
