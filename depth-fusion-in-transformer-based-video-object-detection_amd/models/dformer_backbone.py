@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from dfx import ops as _ops
 from util.memo import memo_on
 from util.misc import NestedTensor
 
@@ -115,12 +116,12 @@ class DFormerBackbone(nn.Module):
                     i += 1
                 gelu = i < len(ops) and isinstance(ops[i], nn.GELU)
                 i += int(gelu)
-                plan.append((w.contiguous(), b.contiguous(), conv.stride, conv.padding, gelu))
+                # hand-written implicit-GEMM convolution, bias + GELU in its epilogue (csrc/conv_igemm.hip)
+                plan.append(_ops.ConvPlan(w, b, conv.stride, conv.padding, conv.dilation, "gelu" if gelu else None))
             self._folded = (key, plan)
-        for w, b, stride, padding, gelu in self._folded[1]:
-            x = F.conv2d(x, w, b, stride, padding)
-            if gelu:
-                x = F.gelu(x)
+        x = x.contiguous()
+        for conv in self._folded[1]:
+            x = conv(x)
         return x
 
     def load_pretrained_weights(self, model, pretrained_weights_path, prefix="downsample_layers_e"):

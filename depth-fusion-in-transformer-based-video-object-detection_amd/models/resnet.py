@@ -9,7 +9,6 @@ torchvision itself is third-party and absent from /root/reference: PARITY UNPINN
 architecture; numerics are plain conv2d and pinned by torch.
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from dfx import ops as _ops
@@ -50,39 +49,41 @@ class Bottleneck(nn.Module):
             mods += [self.downsample[0], self.downsample[1]]
         key = _versions(*mods)
         if self._folded is None or self._folded[0] != key:
-            f = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]
+            c2 = self.conv2
+            scale2, shift2 = self.bn2.scale_shift()
+            # conv2 on the hand-written kernels (Winograd F(2x2,3x3) for stride 1 incl. the dilated stage,
+            # implicit GEMM for stride 2): folded-BN scale in the weights, shift + ReLU in the epilogue
+            plan2 = _ops.ConvPlan(c2.weight, shift2.detach(), c2.stride, c2.padding, c2.dilation, "relu",
+                                  scale=scale2.detach())
+            f = [_fold(self.conv1, self.bn1), plan2, _fold(self.conv3, self.bn3)]
             f.append(_fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None)
             self._folded = (key, f)
         return self._folded[1]
 
     def forward_fused(self, x):
-        """Inference on the GPU: frozen BN folded into the convolutions.  The 1x1 convolutions whose
-        epilogue traffic dominates (conv3 with its residual add + ReLU everywhere; conv1 and the
-        shortcut on the large early maps) run on the hand-written MFMA GEMM with bias / residual /
-        ReLU fused (dfx.ops.conv1x1); the 3x3 convolutions stay on the library with one fused
-        in-place epilogue pass (dfx.ops.bias_act_).  Choice per layer from tools/bench_gemm.py.
-        No CPU route."""
-        (w1, b1), (w2, b2), (w3, b3), down = self._folded_params()
-        c2 = self.conv2
-        big = x.shape[2] * x.shape[3] >= 40000 and (x.shape[2] * x.shape[3]) % 4 == 0
-        gemm_ok = (x.shape[2] * x.shape[3]) % 4 == 0
-        if big:
-            out = _ops.conv1x1(x, w1, b1, relu=True)
-        else:
-            out = _ops.bias_act_(F.conv2d(x, w1), b1, relu=True)
-        out = _ops.bias_act_(F.conv2d(out, w2, None, c2.stride, c2.padding, c2.dilation), b2, relu=True)
+        """Inference on the GPU: frozen BN folded into the convolutions.  The 3x3 convolutions run on the
+        hand-written Winograd / implicit-GEMM kernels (dfx.ops.ConvPlan, csrc/conv_wino.hip,
+        csrc/conv_igemm.hip), the 1x1 convolutions on the hand-written MFMA GEMM (dfx.ops.conv1x1), each
+        with bias / residual / ReLU in its epilogue.  No CPU route."""
+        (w1, b1), plan2, (w3, b3), down = self._folded_params()
+        out = self._conv1x1(0, x, w1, b1, relu=True)
+        out = plan2(out)
         if down is not None:
-            stride = self.downsample[0].stride[0]
-            ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
-            if (big and stride == 1) or (stride == 2 and (ho * wo) % 4 == 0):
-                # the library runs the strided 1x1 shortcut as an NHWC implicit GEMM with transposes
-                # (~1 ms per 8 frames); subsample + MFMA GEMM with the bias fused is ~2x faster
-                x = _ops.conv1x1(x, down[0], down[1], relu=False, stride=stride)
-            else:
-                x = _ops.bias_act_(F.conv2d(x, down[0], None, stride), down[1], relu=False)
-        if gemm_ok and (out.shape[2] * out.shape[3]) % 4 == 0:
-            return _ops.conv1x1(out, w3, b3, residual=x, relu=True)
-        return _ops.bias_act_(F.conv2d(out, w3), b3, residual=x, relu=True)
+            x = self._conv1x1(1, x, down[0], down[1], relu=False, stride=self.downsample[0].stride[0])
+        return self._conv1x1(2, out, w3, b3, relu=True, residual=x)
+
+    def _conv1x1(self, slot, x, w, b, relu, residual=None, stride=1):
+        """1x1 convolution + bias (+ residual) (+ ReLU): the MFMA GEMM over [Ci] x [H*W] when its 16-byte
+        operand rows allow (H*W a multiple of 4: every map of an 800x1333 frame), else the implicit-GEMM
+        convolution (scalar gathers, any geometry) followed by the fused bias / residual / ReLU pass."""
+        ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
+        if (ho * wo) % 4 == 0:
+            return _ops.conv1x1(x, w, b, residual=residual, relu=relu, stride=stride)
+        key = (w.data_ptr(), w._version)
+        plans = self.__dict__.setdefault("_plans1x1", {})
+        if slot not in plans or plans[slot][0] != key:
+            plans[slot] = (key, _ops.ConvPlan(w.reshape(w.shape[0], -1, 1, 1), None, stride, 0, 1, None))
+        return _ops.bias_act_(plans[slot][1](x), b, residual=residual, relu=relu)
 
     def forward(self, x):
         out = self.relu(self.bn1(self.conv1(x)))
@@ -128,9 +129,11 @@ class ResNet50(nn.Module):
             return self.maxpool(self.relu(self.bn1(self.conv1(x))))
         key = _versions(self.conv1, self.bn1)
         if getattr(self, "_stem_folded", None) is None or self._stem_folded[0] != key:
-            self._stem_folded = (key, _fold(self.conv1, self.bn1))
-        w, b = self._stem_folded[1]
-        return _ops.bias_relu_maxpool(F.conv2d(x.contiguous(), w, None, 2, 3), b)
+            scale, shift = self.bn1.scale_shift()
+            self._stem_folded = (key, (_ops.ConvPlan(self.conv1.weight, None, 2, 3, 1, None, scale=scale.detach()),
+                                       shift.detach().contiguous()))
+        plan, b = self._stem_folded[1]
+        return _ops.bias_relu_maxpool(plan(x.contiguous()), b)
 
     def run_stage(self, stage, x, fused=False):
         if not fused:
