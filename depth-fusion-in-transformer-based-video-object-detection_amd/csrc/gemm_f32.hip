@@ -45,6 +45,7 @@ struct Args {
     int cblk;             // > 0: C is stored column-block-major, [ceil(N / cblk)][M][cblk] (include/dfx_gemm.h)
     long cblk_stride;     // elements between column blocks (>= M * cblk)
     long ablk_stride;     // > 0: A is K-block-major, [K / 4][M][4] with this many elements between blocks
+    int wide_epilogue;    // row-major C (and R) with 16-byte aligned rows, N % 4 == 0: float4 epilogue through LDS
 };
 
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
@@ -59,8 +60,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     constexpr int B_LOADS = (B_F4 + 255) / 256;
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad wave layout");
     static_assert(BK % 8 == 0, "a ds_read_b128 covers 8 consecutive k (4 per lane half)");
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][B_KN ? BK * LDB : BN * LDK];   // [k][n] or [n][k]
+    // one LDS object: the two operand stages, re-used by the epilogue as a [64][BN + 4] transpose buffer
+    constexpr int A_SZ = BM * LDK, B_SZ = B_KN ? BK * LDB : BN * LDK;               // floats per stage
+    constexpr int LDC = BN + 4, C_SZ = 64 * LDC;
+    constexpr int S_SZ = 2 * (A_SZ + B_SZ) > C_SZ ? 2 * (A_SZ + B_SZ) : C_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[S_SZ];
+    float (*const As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(smem);        // As[buf][m][k]
+    float (*const Bs)[B_SZ] = reinterpret_cast<float (*)[B_SZ]>(smem + 2 * A_SZ);   // Bs[buf][...]: [k][n] or [n][k]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -196,6 +202,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const float *R = g.R ? g.R + bz * g.strideR : nullptr;
     const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
     const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
+    if (g.wide_epilogue) {
+        // Row-major C with 16-byte aligned rows: the accumulators (a lane holds one column of 16 scattered rows) go
+        // through LDS, 64 tile rows at a time, and leave as float4 per lane - a wave-instruction then covers whole
+        // BN*4-byte row segments (512 B for BN = 128) of C and of the residual instead of 128-byte pieces, with a
+        // quarter of the memory instructions.  The convolutions with many output channels and a short K
+        // (Bottleneck.conv3 + residual) are bound by exactly this traffic.
+        float *Ct = smem;
+#pragma unroll
+        for (int p = 0; p < BM / 64; ++p) {
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if ((wm * TM + i * 32) / 64 != p) continue;           // wave-uniform
+                const int rbase = wm * TM + i * 32 - p * 64 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        Ct[(rbase + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+            }
+            __syncthreads();
+            constexpr int F4 = 64 * BN / 4;
+#pragma unroll
+            for (int f0 = 0; f0 < F4; f0 += 256) {
+                const int f = f0 + tid;
+                if (F4 % 256 != 0 && f >= F4) break;
+                const int row = f / (BN / 4), c4 = f % (BN / 4);
+                const int m = m0 + p * 64 + row, n = n0 + c4 * 4;
+                if (m >= g.M || n >= g.N) continue;
+                float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
+                if (brow) { const float b = g.bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (mask && mask[m]) v = zero4;
+                *reinterpret_cast<float4 *>(C + (long)m * g.ldc + n) = v;
+            }
+        }
+        return;
+    }
     int ncol[NT];
     float bcolv[NT];
     long coff[NT];                                     // element offset of the column inside a C row
@@ -257,8 +303,11 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         return dfx::fail(DFX_EINVAL, "gemm: column-block-major C needs c_block_stride >= M * c_block and no residual");
     if (a_block_stride < 0 || (a_block_stride > 0 && (a_block_stride < (long)M * 4 || (a_block_stride & 3) || A2)))
         return dfx::fail(DFX_EINVAL, "gemm: K-block-major A needs a_block_stride >= 4 * M (a multiple of 4) and no A2");
+    const int wide = c_block == 0 && (N & 3) == 0 && (ldc & 3) == 0 && (strideC & 3) == 0 && dfx::aligned16(C) &&
+                     (!R || ((ldr & 3) == 0 && (strideR & 3) == 0 && dfx::aligned16(R))) &&
+                     (!bias || bias_per_row || dfx::aligned16(bias)) && !getenv("DFX_GEMM_NARROW_EPILOGUE");
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
-           M, N, K, relu, c_block, c_block_stride, a_block_stride};
+           M, N, K, relu, c_block, c_block_stride, a_block_stride, wide};
     hipStream_t st = static_cast<hipStream_t>(stream);
     // tile choice.  Small M / N pick the matching narrow tile.
     if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128

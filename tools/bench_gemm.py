@@ -25,7 +25,8 @@ def timeit(fn, iters=30):
     return a.elapsed_time(b) / iters * 1e-3
 
 
-F = 8  # frames per micro-batch
+F = int(os.environ.get('FRAMES', '8'))  # frames per micro-batch
+LIB = os.environ.get('LIB', '1') == '1'
 print("linear  [M,K] x [N,K]^T")
 for name, M, N, K in (("value_proj", F * 4200, 256, 256), ("qproj", F * 4200, 96, 256), ("ffn1", F * 4200, 1024, 256),
                       ("ffn2", F * 4200, 256, 1024), ("dec 300", F * 300, 256, 256),
@@ -45,7 +46,9 @@ for name, Ci, Co, H, W in (("l1 c1", 256, 64, 200, 334), ("l1 c3", 64, 256, 200,
     x = torch.randn(F, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 1, 1, device="cuda") / Ci ** 0.5
     b = torch.randn(Co, device="cuda")
-    t0 = timeit(lambda: torch.nn.functional.conv2d(x, w))
-    t1 = timeit(lambda: ops.conv1x1(x, w, b, relu=True))
+    res = torch.randn(F, Co, H, W, device="cuda") if "c3" in name else None
+    t0 = timeit(lambda: torch.nn.functional.conv2d(x, w)) if LIB else float("nan")
+    t1 = timeit(lambda: ops.conv1x1(x, w, b, residual=res, relu=True))
     fl = 2.0 * F * H * W * Ci * Co
-    print(f"  {name:8s} Ci={Ci:5d} Co={Co:5d} {H}x{W}  miopen(no epilogue) {t0*1e6:8.1f} us {fl/t0/1e12:6.1f} TF | dfx(+bias+relu) {t1*1e6:8.1f} us {fl/t1/1e12:6.1f} TF", flush=True)
+    gb = 4.0 * F * H * W * (Ci + Co * (2 if res is not None else 1)) / 1e9
+    print(f"  {name:8s} Ci={Ci:5d} Co={Co:5d} {H}x{W}  miopen(no epilogue) {t0*1e6:8.1f} us {fl/t0/1e12:6.1f} TF | dfx(+bias{'+res' if res is not None else ''}+relu) {t1*1e6:8.1f} us {fl/t1/1e12:6.1f} TF {gb/t1/1e3:5.2f} TB/s", flush=True)
