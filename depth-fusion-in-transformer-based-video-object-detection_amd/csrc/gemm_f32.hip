@@ -27,6 +27,7 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct Args {
     const float *A, *A2;
@@ -85,38 +86,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_LOADS], ra2[A_LOADS], rb[B_LOADS];
-    bool oka[A_LOADS], okb[B_LOADS];     // zeroing of out-of-range lanes happens at LDS-store time, so the
-                                         // loads stay in flight across the MFMAs of the current K-step
+    // Operand staging by buffer loads: one wave-uniform descriptor per operand whose size is the operand's exact
+    // extent, a 32-bit byte offset per lane that advances by a constant per K-step.  Rows / columns outside the
+    // problem get an offset beyond every extent (0x80000000; the host checks that an operand stays below 2 GiB),
+    // so the hardware's range check returns zeros for them - no clamps, no selects, no 64-bit address arithmetic in
+    // the loop.  K tails: rows of a [K][N] operand and blocks of a K-block-major A beyond K lie past the extent as
+    // well; for K-contiguous operands the last K-step masks its lanes (wave-uniform branch).
+    constexpr unsigned kOut = 0x80000000u;
+    const long bytesA = g.ablk_stride > 0 ? ((long)(g.K / 4 - 1) * g.ablk_stride + (long)g.M * 4) * 4
+                                          : ((long)(g.M - 1) * g.lda + g.K) * 4;
+    const long bytesB = B_KN ? ((long)(g.K - 1) * g.ldb + g.N) * 4 : ((long)(g.N - 1) * g.ldb + g.K) * 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A2 ? A2 : A), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bytesB, 0x00020000);
+    unsigned va[A_LOADS], vb[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int f = tid + i * 256, row = f / KQ, kq = f % KQ, m = m0 + row;
+        const unsigned o = g.ablk_stride > 0 ? ((unsigned)kq * (unsigned)g.ablk_stride + (unsigned)m * 4u) * 4u
+                                             : ((unsigned)m * (unsigned)g.lda + (unsigned)kq * 4u) * 4u;
+        va[i] = (m < g.M && f < A_F4) ? o : kOut;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int f = tid + i * 256;
+        if (B_KN) {
+            const int kr = f / (BN / 4), nq = f % (BN / 4), n = n0 + nq * 4;
+            vb[i] = (n < g.N && f < B_F4) ? ((unsigned)kr * (unsigned)g.ldb + (unsigned)n) * 4u : kOut;
+        } else {
+            const int row = f / KQ, kq = f % KQ, n = n0 + row;
+            vb[i] = (n < g.N && f < B_F4) ? ((unsigned)n * (unsigned)g.ldb + (unsigned)kq * 4u) * 4u : kOut;
+        }
+    }
+    const unsigned stepA = g.ablk_stride > 0 ? (unsigned)(BK / 4) * (unsigned)g.ablk_stride * 4u : BK * 4u;
+    const unsigned stepB = B_KN ? (unsigned)BK * (unsigned)g.ldb * 4u : BK * 4u;
 
-    // loads are unconditional: indices are clamped into the operand and out-of-range lanes are
-    // zeroed by a select afterwards, so the compiler can keep every load of a K-step in flight
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 ra[A_LOADS], ra2[A_LOADS], rb[B_LOADS];
+    bool ktail = false;                   // the loaded K-step reaches past K (wave-uniform)
+    int ktail_k0 = 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tiles = [&](int k0) {
+        ktail = k0 + BK > g.K;
+        ktail_k0 = k0;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * 256, row = f / KQ, kq = f % KQ;
-            const int m = m0 + row, k = k0 + kq * 4;
-            oka[i] = m < g.M && k < g.K;
-            const int mc = min(m, g.M - 1), kc = min(k, g.K - 4);
-            const long o = g.ablk_stride > 0 ? (long)(kc >> 2) * g.ablk_stride + (long)mc * 4 : (long)mc * g.lda + kc;
-            ra[i] = *reinterpret_cast<const float4 *>(A + o);
-            if (A2) ra2[i] = *reinterpret_cast<const float4 *>(A2 + o);
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, va[i], 0, 0));
+            if (A2) ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, va[i], 0, 0));
+            va[i] += stepA;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int f = tid + i * 256;
-            if (B_KN) {
-                const int kr = f / (BN / 4), nq = f % (BN / 4);
-                const int k = k0 + kr, n = n0 + nq * 4;
-                okb[i] = k < g.K && n < g.N;
-                rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
-            } else {
-                const int row = f / KQ, kq = f % KQ;
-                const int n = n0 + row, k = k0 + kq * 4;
-                okb[i] = n < g.N && k < g.K;
-                rb[i] = *reinterpret_cast<const float4 *>(B + (long)min(n, g.N - 1) * g.ldb + min(k, g.K - 4));
-            }
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vb[i], 0, 0));
+            vb[i] += stepB;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -124,22 +145,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
         for (int i = 0; i < A_LOADS; ++i) {
             const int f = tid + i * 256, row = f / KQ, kq = f % KQ;
             if (f >= A_F4) continue;
-            float4 v = ra[i];
-            if (A2) { v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w; }
-            if (!oka[i]) v = zero4;
-            *reinterpret_cast<float4 *>(&As[buf][row][kq * 4]) = v;
+            f32x4 v = ra[i];
+            if (A2) v += ra2[i];
+            if (ktail && g.ablk_stride == 0 && ktail_k0 + kq * 4 >= g.K) v = zero4;
+            *reinterpret_cast<f32x4 *>(&As[buf][row][kq * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int f = tid + i * 256;
             if (f >= B_F4) continue;
-            const float4 v = okb[i] ? rb[i] : zero4;
             if (B_KN) {
                 const int kr = f / (BN / 4), nq = f % (BN / 4);
-                *reinterpret_cast<float4 *>(&Bs[buf][kr * LDB + nq * 4]) = v;
+                *reinterpret_cast<f32x4 *>(&Bs[buf][kr * LDB + nq * 4]) = rb[i];
             } else {
                 const int row = f / KQ, kq = f % KQ;
-                *reinterpret_cast<float4 *>(&Bs[buf][row * LDK + kq * 4]) = v;
+                f32x4 v = rb[i];
+                if (ktail && ktail_k0 + kq * 4 >= g.K) v = zero4;
+                *reinterpret_cast<f32x4 *>(&Bs[buf][row * LDK + kq * 4]) = v;
             }
         }
     };
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                 if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (mask && mask[m]) v = zero4;
+                if (mask && mask[m]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(C + (long)m * g.ldc + n) = v;
             }
         }
@@ -299,6 +321,11 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         (A2 && !dfx::aligned16(A2)) || (b_is_kn && (N & 3)))
         return dfx::fail(DFX_EINVAL, "gemm: K (and N for [K,N] operands) must be multiples of 4, rows 16-byte aligned");
     if (batch > 65535) return dfx::fail(DFX_ERANGE, "gemm: batch too large");
+    {   // 32-bit byte offsets inside one batch element's operands (buffer loads)
+        const long ea = a_block_stride > 0 ? (long)(K / 4) * a_block_stride : (long)M * lda;
+        const long eb = b_is_kn ? (long)K * ldb : (long)N * ldb;
+        if (ea * 4 >= (1L << 31) || eb * 4 >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: an operand exceeds 2 GiB per batch element");
+    }
     if (c_block < 0 || (c_block > 0 && (c_block_stride < (long)M * c_block || R)))
         return dfx::fail(DFX_EINVAL, "gemm: column-block-major C needs c_block_stride >= M * c_block and no residual");
     if (a_block_stride < 0 || (a_block_stride > 0 && (a_block_stride < (long)M * 4 || (a_block_stride & 3) || A2)))

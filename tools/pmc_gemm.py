@@ -12,15 +12,16 @@ from dfx import ops  # noqa: E402
 
 torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
+FR = int(os.environ.get("FRAMES", "8"))
 for Ci, Co, H, W in ((1024, 2048, 50, 84), (512, 2048, 50, 84), (64, 256, 200, 334), (2048, 256, 50, 84)):
-    x = torch.randn(8, Ci, H, W, device="cuda")
+    x = torch.randn(FR, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 1, 1, device="cuda") / Ci ** 0.5
     b = torch.randn(Co, device="cuda")
     for _ in range(3):
         ops.conv1x1(x, w, b, relu=True)
     for _ in range(3):
         F.conv2d(x, w)
-for M, N, K in ((33600, 256, 256), (33600, 1024, 256), (33600, 256, 1024), (33600, 96, 256)):
+for M, N, K in ((4200 * FR, 256, 256), (4200 * FR, 1024, 256), (4200 * FR, 256, 1024), (4200 * FR, 96, 256), (300 * FR, 256, 12544)):
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / 16
     b = torch.randn(N, device="cuda")
