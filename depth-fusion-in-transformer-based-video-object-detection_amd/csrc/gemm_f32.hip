@@ -47,7 +47,13 @@ struct Args {
     long cblk_stride;     // elements between column blocks (>= M * cblk)
     long ablk_stride;     // > 0: A is K-block-major, [K / 4][M][4] with this many elements between blocks
     int wide_epilogue;    // row-major C (and R) with 16-byte aligned rows, N % 4 == 0: float4 epilogue through LDS
+    int splits, kper;     // split-K: blockIdx.z = batch * splits + split, split s covers k in [s * kper, min(K, (s + 1) * kper))
 };
+
+__device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: exact (erf) GELU
+{
+    return act == 1 ? fmaxf(v, 0.f) : 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
 
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
@@ -73,10 +79,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, c = lane & 31;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const long bz = blockIdx.z;
-    const float *A = g.A + bz * g.strideA;
-    const float *A2 = g.A2 ? g.A2 + bz * g.strideA : nullptr;
-    const float *B = g.B + bz * g.strideB;
+    long bz = blockIdx.z;
+    const long cz = bz;                                   // C slice: one per (batch, split)
+    int kbeg = 0, K = g.K;                                // this workgroup's K range
+    if (g.splits > 1) {
+        const int split = (int)(bz % g.splits);
+        bz /= g.splits;
+        kbeg = split * g.kper;
+        K = min(g.K - kbeg, g.kper);
+    }
+    const long ashift = g.ablk_stride > 0 ? (long)(kbeg >> 2) * g.ablk_stride : (long)kbeg;
+    const float *A = g.A + bz * g.strideA + ashift;
+    const float *A2 = g.A2 ? g.A2 + bz * g.strideA + ashift : nullptr;
+    const float *B = g.B + bz * g.strideB + (B_KN ? (long)kbeg * g.ldb : (long)kbeg);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -93,9 +108,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     // the loop.  K tails: rows of a [K][N] operand and blocks of a K-block-major A beyond K lie past the extent as
     // well; for K-contiguous operands the last K-step masks its lanes (wave-uniform branch).
     constexpr unsigned kOut = 0x80000000u;
-    const long bytesA = g.ablk_stride > 0 ? ((long)(g.K / 4 - 1) * g.ablk_stride + (long)g.M * 4) * 4
-                                          : ((long)(g.M - 1) * g.lda + g.K) * 4;
-    const long bytesB = B_KN ? ((long)(g.K - 1) * g.ldb + g.N) * 4 : ((long)(g.N - 1) * g.ldb + g.K) * 4;
+    const long bytesA = g.ablk_stride > 0 ? ((long)(K / 4 - 1) * g.ablk_stride + (long)g.M * 4) * 4
+                                          : ((long)(g.M - 1) * g.lda + K) * 4;
+    const long bytesB = B_KN ? ((long)(K - 1) * g.ldb + g.N) * 4 : ((long)(g.N - 1) * g.ldb + K) * 4;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A2 ? A2 : A), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bytesB, 0x00020000);
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     int ktail_k0 = 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tiles = [&](int k0) {
-        ktail = k0 + BK > g.K;
+        ktail = k0 + BK > K;
         ktail_k0 = k0;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             if (f >= A_F4) continue;
             f32x4 v = ra[i];
             if (A2) v += ra2[i];
-            if (ktail && g.ablk_stride == 0 && ktail_k0 + kq * 4 >= g.K) v = zero4;
+            if (ktail && g.ablk_stride == 0 && ktail_k0 + kq * 4 >= K) v = zero4;
             *reinterpret_cast<f32x4 *>(&As[buf][row][kq * 4]) = v;
         }
 #pragma unroll
@@ -160,13 +175,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             } else {
                 const int row = f / KQ, kq = f % KQ;
                 f32x4 v = rb[i];
-                if (ktail && ktail_k0 + kq * 4 >= g.K) v = zero4;
+                if (ktail && ktail_k0 + kq * 4 >= K) v = zero4;
                 *reinterpret_cast<f32x4 *>(&Bs[buf][row * LDK + kq * 4]) = v;
             }
         }
     };
 
-    const int steps = (g.K + BK - 1) / BK;
+    const int steps = (K + BK - 1) / BK;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     }
 
     // ---- epilogue ----
-    float *C = g.C + bz * g.strideC;
+    float *C = g.C + cz * g.strideC;
     const float *R = g.R ? g.R + bz * g.strideR : nullptr;
     const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
     const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 if (brow) { const float b = g.bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
                 if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
                 if (mask && mask[m]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(C + (long)m * g.ldc + n) = v;
             }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             for (int j = 0; j < NT; ++j) {
                 float v = acc[i][j][r] + bcolv[j] + rb;
                 if (R) v += R[(long)mc * g.ldr + min(ncol[j], g.N - 1)];
-                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.relu) v = activate(v, g.relu);
                 if (rz) v = 0.f;
                 if (m < g.M && ncol[j] < g.N) C[(long)m * rowmul + coff[j]] = v;
             }
@@ -298,13 +313,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 template <int BM, int BN, int WM, int WN, int BK = 16>
 int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
 {
-    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch), block(256);
+    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * (g.splits > 1 ? g.splits : 1)), block(256);
     if (b_is_kn)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, BK>), grid, block, 0, st, g);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, BK>), grid, block, 0, st, g);
     return dfx::check_launch("gemm_f32_kernel");
 }
+
+int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st);
 
 }  // namespace
 
@@ -334,8 +351,16 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
                      (!R || ((ldr & 3) == 0 && (strideR & 3) == 0 && dfx::aligned16(R))) &&
                      (!bias || bias_per_row || dfx::aligned16(bias)) && !getenv("DFX_GEMM_NARROW_EPILOGUE");
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
-           M, N, K, relu, c_block, c_block_stride, a_block_stride, wide};
-    hipStream_t st = static_cast<hipStream_t>(stream);
+           M, N, K, relu, c_block, c_block_stride, a_block_stride, wide, 1, K};
+    return choose_and_launch(g, batch, b_is_kn, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+
+int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
+{
+    const int M = g.M, N = g.N, K = g.splits > 1 ? g.kper : g.K;
+    const long zb = (long)batch * (g.splits > 1 ? g.splits : 1);
     // tile choice.  Small M / N pick the matching narrow tile.
     if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128
         if (force[0] == '0') return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
@@ -354,11 +379,63 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     // operand reuse), and the 64 x 128 tile - 6 waves per SIMD - is the most even performer; the
     // 128 x 128 tile is kept for the large, deep convolutions of layer4 where it is 2-3 % ahead.
     if (M >= 1024 && (long)N * batch >= 16384 && K >= 512 && K <= 1024) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    if (K >= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) * zb >= 8 * 768) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     // Few tiles (token GEMMs of a 4- or 8-frame rank block): all workgroups are resident at once, the CUs that get
     // one tile more than the others set the time.  A 64 x 64 tile halves that quantum (M = 16800, N = 256:
     // 526 tiles of 64 x 128 = 3 on some CUs, 2.05 on average; 1052 of 64 x 64 = 5 against 4.1).
     auto fill = [](long tiles) { return (double)tiles / (256.0 * (double)((tiles + 255) / 256)); };
-    const long t128 = (long)((M + 63) / 64) * ((N + 127) / 128) * batch, t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    const long t128 = (long)((M + 63) / 64) * ((N + 127) / 128) * zb, t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * zb;
     if (t128 < 8 * 256 && 0.95 * fill(t64) > fill(t128)) return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
+}
+
+// ---- split-K ------------------------------------------------------------------------------------------
+// out = act(sum_s ws[s] + bias (+ R)), float4 per thread
+__global__ void splitk_reduce_kernel(const float *ws, int splits, long MN, int N, const float *bias, int bias_per_row,
+                                     const float *R, long ldr, int act, float *C, long ldc)
+{
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= MN) return;
+    const long e = i4 * 4;
+    const int m = (int)(e / N), n = (int)(e - (long)m * N);
+    float4 v = *reinterpret_cast<const float4 *>(ws + e);
+    for (int s = 1; s < splits; ++s) {
+        const float4 q = *reinterpret_cast<const float4 *>(ws + (long)s * MN + e);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if (bias) {
+        if (bias_per_row) { const float b = bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        else { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+    }
+    if (R) { const float *r = R + (long)m * ldr + n; v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3]; }
+    if (act) { v.x = activate(v.x, act); v.y = activate(v.y, act); v.z = activate(v.z, act); v.w = activate(v.w, act); }
+    float *c = C + (long)m * ldc + n;
+    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+}
+
+}  // namespace
+
+extern "C" int dfx_gemm_splitk_f32(const float *A, long lda, const float *B, long ldb, int b_is_kn, const float *bias,
+                                   int bias_per_row, const float *R, long ldr, float *C, long ldc, int M, int N, int K,
+                                   int act, int splits, float *workspace, void *stream)
+{
+    if (M < 0 || N < 0 || K <= 0 || splits < 1) return dfx::fail(DFX_EINVAL, "gemm_splitk: bad dimension");
+    if ((long)M * N == 0) return DFX_OK;
+    if (!A || !B || !C || !workspace) return dfx::fail(DFX_EINVAL, "gemm_splitk: null pointer");
+    if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !dfx::aligned16(A) || !dfx::aligned16(B) || !dfx::aligned16(workspace))
+        return dfx::fail(DFX_EINVAL, "gemm_splitk: K and N must be multiples of 4, rows and the workspace 16-byte aligned");
+    if ((long)M * lda * 4 >= (1L << 31) || (long)(b_is_kn ? K : N) * ldb * 4 >= (1L << 31))
+        return dfx::fail(DFX_ERANGE, "gemm_splitk: an operand exceeds 2 GiB");
+    int kper = ((K + splits - 1) / splits + 15) / 16 * 16;          // whole K-steps per split
+    splits = (K + kper - 1) / kper;
+    if (splits > 65535) return dfx::fail(DFX_ERANGE, "gemm_splitk: too many splits");
+    Args g{A, nullptr, lda, 0, B, ldb, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, workspace, (long)N, (long)M * N,
+           M, N, K, 0, 0, 0, 0, 1, splits, kper};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rc = choose_and_launch(g, 1, b_is_kn, st);
+    if (rc != DFX_OK) return rc;
+    const long quads = ((long)M * N + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, workspace, splits,
+                       (long)M * N, N, bias, bias_per_row, R, ldr, act, C, ldc);
+    return dfx::check_launch("splitk_reduce_kernel");
 }

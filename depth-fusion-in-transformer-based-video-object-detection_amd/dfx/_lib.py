@@ -30,11 +30,13 @@ SIGNATURES = {
     "dfx_preprocess_u8_f32": [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _p, _p],
     # include/dfx_gemm.h
     "dfx_gemm_f32": [_p, _p, _l, _l, _p, _l, _l, _i, _p, _i, _p, _l, _l, _p, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _p],
+    "dfx_gemm_splitk_f32": [_p, _l, _p, _l, _i, _p, _i, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _p],
     # include/dfx_fused.h: x, bias, residual, out, N, C, HW, relu, stream
     "dfx_bias_act_nchw_f32": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
     "dfx_bias_relu_maxpool_f32": [_p, _p, _p, _i, _i, _i, _i, _p],
     "dfx_add_layernorm_f32": [_p, _p, _p, _p, _p, _l, _i, ctypes.c_float, _p],
     "dfx_box_refine_f32": [_p, _p, _i, _p, _l, ctypes.c_float, _p],
+    "dfx_group_norm_f32": [_p, _p, _p, _p, _p, _i, _i, _l, _i, ctypes.c_float, _i, _p],
     # include/dfx_conv.h
     "dfx_conv2d_igemm_f32": [_p, _p, _p, _p, _p] + [_i] * 11 + [_p],
     "dfx_conv3x3_wino_f32": [_p, _p, _p, _p] + [_i] * 7 + [_p],

@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64"}
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 
 # Single-level attention with many queries (encoder, depth fusion) runs on the level-in-LDS kernel
 # (csrc/msda_level.hip) when the level fits the CU's LDS; DFX_MSDA_LEVEL=0 keeps the wave-per-query
@@ -264,8 +265,19 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False):
+def _split_k(M, N, K):
+    """Number of K ranges for a GEMM with few output tiles and a long K (0 = no split): aim at ~3 workgroups per
+    CU, at least 32 K-steps per range."""
+    tiles = -(-M // 64) * -(-N // 128)
+    if tiles >= 512 or K < 2048:
+        return 0
+    return max(1, min(K // 512, 768 // tiles))
+
+
+def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False,
+           act=None):
     """y = act((x (+ add)) @ weight.T + bias (+ residual)), rows where row_mask is True set to 0.
+    act: None / "relu" / "gelu" (``relu=True`` is the older spelling of act="relu").
     The hand-written fp32 MFMA GEMM (include/dfx_gemm.h) standing in for nn.Linear with its
     neighbours fused: the ``src + pos`` query add, the bias, ReLU, the residual add and
     value_proj's masked_fill.  x [..., K] contiguous, weight [N, K] -> [..., N].
@@ -304,10 +316,18 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
     if row_mask is not None:
         _require(row_mask.numel() == M, "row_mask must have one entry per row")
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
+    code = ACT[act] if act is not None else int(bool(relu))
+    splits = _split_k(M, N, K) if (add is None and row_mask is None and not col_block and not x_blocked and N % 4 == 0) else 0
     with torch.cuda.device(x.device):
+        if splits > 1:
+            ws = torch.empty((splits, M, N), dtype=torch.float32, device=x.device)
+            rc = lib.dfx_gemm_splitk_f32(x2.data_ptr(), K, weight.data_ptr(), K, 0, _ptr(bias), 0, _ptr(residual), N,
+                                         out.data_ptr(), N, M, N, K, code, splits, ws.data_ptr(), _stream(x.device))
+            _lib.check(rc, "linear (split-K)")
+            return out
         rc = lib.dfx_gemm_f32(x2.data_ptr(), _ptr(add), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), 0,
                               _ptr(residual), N, 0, _ptr(row_mask), 0, out.data_ptr(), N, 0, M, N, K, 1,
-                              int(bool(relu)), int(col_block), M * int(col_block), M * 4 if x_blocked else 0,
+                              code, int(col_block), M * int(col_block), M * 4 if x_blocked else 0,
                               _stream(x.device))
     _lib.check(rc, "linear")
     return out
@@ -433,8 +453,6 @@ def bias_relu_maxpool(x, bias):
     return out
 
 
-ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
-
 
 class ConvPlan:
     """One convolution prepared for the hand-written kernels (include/dfx_conv.h): 3x3 / stride 1 / "same"
@@ -495,3 +513,22 @@ class ConvPlan:
                                               self.padding, self.act, _stream(x.device))
         _lib.check(rc, "conv " + self.algo)
         return y
+
+
+def group_norm(x, norm, tokens_out=False):
+    """nn.GroupNorm ``norm`` applied to x [N,C,H,W] (contiguous NCHW) in two streaming launches
+    (include/dfx_fused.h, dfx_group_norm_f32).  tokens_out: the result is written token-major [N,H*W,C] and
+    returned as an NCHW-shaped VIEW of that memory, so ``y.flatten(2).transpose(1, 2)`` - what the transformer
+    does next - is already contiguous and costs nothing."""
+    lib = _lib.load()
+    _check_inputs([("x", x), ("weight", norm.weight), ("bias", norm.bias)])
+    _require(x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == norm.num_channels, "group_norm: fp32 NCHW")
+    N, C, H, W = x.shape
+    stats = torch.empty(N * norm.num_groups * 2, dtype=torch.float32, device=x.device)
+    y = torch.empty((N, H * W, C) if tokens_out else (N, C, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dfx_group_norm_f32(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), stats.data_ptr(),
+                                    y.data_ptr(), N, C, H * W, norm.num_groups, float(norm.eps), int(bool(tokens_out)),
+                                    _stream(x.device))
+    _lib.check(rc, "group_norm")
+    return y.transpose(1, 2).unflatten(2, (H, W)) if tokens_out else y

@@ -5,6 +5,8 @@ transformer that takes only the last class head (:281).
 import torch
 from torch import nn
 
+from models.fused import Linear
+
 from util.misc_multi import NestedTensor, nested_tensor_from_tensor_list
 
 from .deformable_transformer_multi import build_deforamble_transformer
@@ -21,7 +23,7 @@ class DeformableDETR(DetectorBase):
         self._init_common(backbone, depth_backbone, transformer, num_classes, num_queries, num_feature_levels,
                           aux_loss, with_box_refine, two_stage, use_depth, depth_type)
         hidden = transformer.d_model
-        self.temp_class_embed = nn.Linear(hidden, num_classes)
+        self.temp_class_embed = Linear(hidden, num_classes)
         self.temp_bbox_embed = MLP(hidden, hidden, 4, 3)
         self.temp_class_embed.bias.data = _prior_bias(num_classes)
         _zero_last_layer(self.temp_bbox_embed)

@@ -9,6 +9,8 @@ import copy
 import torch
 from torch import nn
 
+from models.fused import Linear
+
 from util.misc_multi import NestedTensor, inverse_sigmoid, nested_tensor_from_tensor_list
 
 from .deformable_transformer_multi_plusplus import build_deforamble_transformer
@@ -26,7 +28,7 @@ class DeformableDETR(DetectorBase):
                           aux_loss, with_box_refine, two_stage, use_depth, depth_type)
         hidden = transformer.d_model
         # heads of the temporal stage: one template, three independent copies (one per TQE/TDTD round)
-        self.temp_class_embed = nn.Linear(hidden, num_classes)
+        self.temp_class_embed = Linear(hidden, num_classes)
         self.temp_bbox_embed = MLP(hidden, hidden, 4, 3)
         self.temp_class_embed.bias.data = _prior_bias(num_classes)
         _zero_last_layer(self.temp_bbox_embed)

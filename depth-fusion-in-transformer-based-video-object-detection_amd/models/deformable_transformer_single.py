@@ -8,6 +8,8 @@ import math
 
 import torch
 from torch import nn
+
+from models.fused import Linear
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from models.ops.modules import MSDeformAttn
@@ -57,12 +59,12 @@ class SpatialTransformerBase(nn.Module):
         self.decoder = DeformableTransformerDecoder(dec_layer, num_decoder_layers, return_intermediate_dec)
         self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
         if two_stage:
-            self.enc_output = nn.Linear(d_model, d_model)
+            self.enc_output = Linear(d_model, d_model)
             self.enc_output_norm = nn.LayerNorm(d_model)
-            self.pos_trans = nn.Linear(d_model * 2, d_model * 2)
+            self.pos_trans = Linear(d_model * 2, d_model * 2)
             self.pos_trans_norm = nn.LayerNorm(d_model * 2)
         else:
-            self.reference_points = nn.Linear(d_model, 2)
+            self.reference_points = Linear(d_model, 2)
         return dec_layer
 
     def _reset_parameters(self):

@@ -9,6 +9,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from dfx import ops as _ops
+from models.fused import Linear
+
 from util import box_ops
 from util.memo import memo_on
 from util.misc import NestedTensor, inverse_sigmoid
@@ -25,7 +28,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 4 == 0
@@ -42,8 +45,29 @@ class MLP(nn.Module):
         return x
 
 
+class _ConvGN(nn.Sequential):
+    """Conv2d + GroupNorm(32) of the input projections (ref deformable_detr_single.py:101-125).  GPU inference:
+    the convolution on the hand-written kernels (1x1: MFMA GEMM with the bias in its epilogue; 3x3/2 of the extra
+    levels: implicit GEMM), GroupNorm as two streaming launches that write token-major memory (dfx.ops.group_norm)."""
+
+    def forward(self, x):
+        conv, norm = self[0], self[1]
+        if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+            return super().forward(x)
+        x = x.contiguous()
+        hw = x.shape[2] * x.shape[3]
+        if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and hw % 4 == 0 and x.shape[1] % 4 == 0:
+            y = _ops.conv1x1(x, conv.weight, conv.bias)
+        else:
+            key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version)
+            if getattr(self, "_plan", (None,))[0] != key:
+                self._plan = (key, _ops.ConvPlan(conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation))
+            y = self._plan[1](x)
+        return _ops.group_norm(y, norm, tokens_out=True)
+
+
 def _conv_gn(cin, cout, kernel_size=1, **kw):
-    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=kernel_size, **kw), nn.GroupNorm(32, cout))
+    return _ConvGN(nn.Conv2d(cin, cout, kernel_size=kernel_size, **kw), nn.GroupNorm(32, cout))
 
 
 def _prior_bias(num_classes, prior_prob=0.01):
@@ -84,7 +108,7 @@ class DetectorBase(nn.Module):
         self.with_box_refine, self.two_stage = with_box_refine, two_stage
         self.transformer = transformer
         hidden = transformer.d_model
-        self.class_embed = nn.Linear(hidden, num_classes)
+        self.class_embed = Linear(hidden, num_classes)
         self.bbox_embed = MLP(hidden, hidden, 4, 3)
         self.num_feature_levels = num_feature_levels
         self.num_channels = dict(self.NUM_CHANNELS)

@@ -17,6 +17,8 @@ from typing import List
 import torch
 from torch import nn
 
+from models.fused import Linear
+
 from models.ops.modules import MSDeformAttn
 from util.misc import NestedTensor
 
@@ -39,13 +41,13 @@ class DepthDeformableTransformerEncoderLayer(nn.Module):
         self.cross_attn = MSDeformAttn(d_model, n_depth_levels, n_heads, dpth_n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_model)
+        self.linear1 = Linear(d_model, d_model)
         self.activation = _get_activation_fn(activation)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
-        self.depth_scale_adapt = nn.Linear(d_model, d_model)
+        self.depth_scale_adapt = Linear(d_model, d_model)
         self.norm_depth_scale = nn.LayerNorm(d_model)
-        self.cross_scale_adapt = nn.Linear(d_model, d_model)
+        self.cross_scale_adapt = Linear(d_model, d_model)
 
     with_pos_embed = staticmethod(_add_pos)
 

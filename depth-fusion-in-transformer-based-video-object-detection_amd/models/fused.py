@@ -15,3 +15,19 @@ def enable_fused_inference(model, enabled=True):
             mod.fused_inference = enabled
             n += 1
     return n
+
+
+import torch
+from torch import nn
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose no-grad fp32 forward on the GPU is the hand-written
+    MFMA GEMM with the bias in its epilogue (dfx.ops.linear, csrc/gemm_f32.hip); anything else is nn.Linear."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self.in_features % 4 == 0
+                and x.numel() > 0):
+            from dfx import ops
+            return ops.linear(x.contiguous(), self.weight, self.bias)
+        return super().forward(x)

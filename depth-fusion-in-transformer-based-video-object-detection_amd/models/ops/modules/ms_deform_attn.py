@@ -20,6 +20,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from models.fused import Linear
+
 from dfx import ops as _ops
 from ..functions import ms_deform_attn_func as _func
 
@@ -41,10 +43,10 @@ class MSDeformAttn(nn.Module):
         self.im2col_step = 64
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
         mlp = n_heads * n_levels * n_points
-        self.sampling_offsets = nn.Linear(d_model, mlp * 2)
-        self.attention_weights = nn.Linear(d_model, mlp)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = Linear(d_model, mlp * 2)
+        self.attention_weights = Linear(d_model, mlp)
+        self.value_proj = Linear(d_model, d_model)
+        self.output_proj = Linear(d_model, d_model)
         self._qproj_cache = None
         self._reset_parameters()
 
@@ -109,7 +111,8 @@ class MSDeformAttn(nn.Module):
         if ref_dim not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {ref_dim} instead.")
 
-        no_grad = not torch.is_grad_enabled() or not (query.requires_grad or input_flatten.requires_grad)
+        q_parts = query if isinstance(query, tuple) else (query,)
+        no_grad = not torch.is_grad_enabled() or not (any(t.requires_grad for t in q_parts) or input_flatten.requires_grad)
         fused = no_grad and input_flatten.is_cuda and input_flatten.dtype == torch.float32 \
             and _ops.fused_supported(input_flatten, M, D, L, P, reference_points.shape[2])
         host = getattr(input_spatial_shapes, "_dfx_host", None)
@@ -127,20 +130,11 @@ class MSDeformAttn(nn.Module):
         if fused:
             # value_proj (+ masked_fill of padded tokens), [offsets | logits] in one GEMM (+ the
             # caller's ``src + pos`` add when handed over as a (src, pos) pair), fused sampling
-            big = N * S >= 2048       # hand-written MFMA GEMM pays off on the token-sized calls
             q, q_add = query if isinstance(query, tuple) else (query, None)
             w, b = self._qproj_params()
-            if big:
-                value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
-                                    row_mask=input_padding_mask)
-            else:
-                value = self.value_proj(input_flatten)
-                if input_padding_mask is not None:
-                    value = value.masked_fill(input_padding_mask[..., None], float(0))
-            if N * Lq >= 2048:
-                qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous())
-            else:
-                qproj = F.linear(q if q_add is None else q + q_add, w, b)
+            value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
+                                row_mask=input_padding_mask)
+            qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous())
             sampled = _ops.msda_fused_forward(value.view(N, S, M, D), input_spatial_shapes, input_level_start_index,
                                               reference_points, qproj, L, P)
             return self.output_proj(sampled)

@@ -12,6 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from models.fused import Linear
+
 _DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
 
 
@@ -28,12 +30,12 @@ class DynamicConv(nn.Module):
         sp = cfg["MODEL"]["SparseRCNN"]
         self.hidden_dim, self.dim_dynamic, self.num_dynamic = sp["HIDDEN_DIM"], sp["DIM_DYNAMIC"], sp["NUM_DYNAMIC"]
         self.num_params = self.hidden_dim * self.dim_dynamic
-        self.dynamic_layer = nn.Linear(self.hidden_dim, self.num_dynamic * self.num_params)
+        self.dynamic_layer = Linear(self.hidden_dim, self.num_dynamic * self.num_params)
         self.norm1 = nn.LayerNorm(self.dim_dynamic)
         self.norm2 = nn.LayerNorm(self.hidden_dim)
         self.activation = nn.ReLU(inplace=True)
         res = cfg["MODEL"]["ROI_BOX_HEAD"]["POOLER_RESOLUTION"]
-        self.out_layer = nn.Linear(self.hidden_dim * res ** 2, self.hidden_dim)
+        self.out_layer = Linear(self.hidden_dim * res ** 2, self.hidden_dim)
         self.norm3 = nn.LayerNorm(self.hidden_dim)
 
     def forward(self, pro_features, roi_features):
@@ -64,9 +66,9 @@ class RCNNHead(nn.Module):
         self.d_model = d_model
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.inst_interact = DynamicConv(cfg)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)

@@ -17,6 +17,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from models.fused import Linear
+
 from models.ops.modules import MSDeformAttn
 from util.memo import memo_on
 from util.misc import inverse_sigmoid
@@ -133,10 +135,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -197,18 +199,22 @@ class _CrossFusionBlock(nn.Module):
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_model)
+        self.linear1 = Linear(d_model, d_model)
         self.activation = _get_activation_fn("gelu")
         setattr(self, self._ffn_drop, nn.Dropout(dropout))
         setattr(self, self._ffn_norm, nn.LayerNorm(d_model))
-        self.depth_scale_adapt = nn.Linear(d_model, d_model)
+        self.depth_scale_adapt = Linear(d_model, d_model)
         self.norm_depth_scale = nn.LayerNorm(d_model)
-        self.cross_scale_adapt = nn.Linear(d_model, d_model)
+        self.cross_scale_adapt = Linear(d_model, d_model)
 
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.activation(self.linear1(tgt))
+        if (self.activation is F.gelu and tgt.is_cuda and tgt.dtype == torch.float32 and not torch.is_grad_enabled()):
+            from dfx import ops as _ops            # Linear + bias + exact GELU in one MFMA GEMM
+            y = _ops.linear(tgt.contiguous(), self.linear1.weight, self.linear1.bias, act="gelu")
+        else:
+            y = self.activation(self.linear1(tgt))
         return _norm_add(getattr(self, self._ffn_norm), tgt, getattr(self, self._ffn_drop)(y))
 
     def _fuse(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask):
@@ -294,10 +300,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 
@@ -394,10 +400,10 @@ class TemporalQueryEncoderLayer(nn.Module):
         self.cross_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 
@@ -442,10 +448,10 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 

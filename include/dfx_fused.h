@@ -43,6 +43,15 @@ int dfx_add_layernorm_f32(const float *x, const float *res, const float *gamma, 
 int dfx_box_refine_f32(const float *delta, const float *ref, int ref_dim, float *out, long rows, float eps,
                        void *stream);
 
+/* nn.GroupNorm(groups, C) of the detector's input projections (Conv1x1 + GroupNorm(32, 256),
+ * /root/reference/models/deformable_detr_single.py:101-125,143-150): biased variance over each group's C/groups
+ * channels x HW pixels, eps inside the sqrt, per-channel affine.
+ *   x [N,C,HW] NCHW;  stats [N*groups*2] scratch (mean, rstd), caller-owned
+ *   y: tokens_out = 0 -> [N,C,HW];  tokens_out = 1 -> [N,HW,C]  (the layout the transformer flattens to, so the
+ *      reference's separate flatten(2).transpose(1,2) copy is not needed) */
+int dfx_group_norm_f32(const float *x, const float *gamma, const float *beta, float *stats, float *y,
+                       int N, int C, long HW, int groups, float eps, int tokens_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

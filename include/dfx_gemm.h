@@ -27,8 +27,16 @@
  *       C[(n / w) * c_block_stride + m * w + n % w] - the layout the level-in-LDS MSDA kernel
  *       (dfx_msda.h) reads: value_proj output as [32 channel octets][tokens][8], the joint
  *       sampling_offsets / attention_weights output as [8 heads][queries][12] (no residual then)
+ *   relu 0: none, 1: ReLU, 2: exact (erf) GELU (nn.GELU() of the fusion blocks' FFN,
+ *       /root/reference/models/deformable_transformer_single.py:379-402)
  * fp32 in, fp32 accumulate (exact fp32 MFMA), fp32 out.  K must be a multiple of 4; A, B rows
  * 16-byte aligned.  Same conventions as dfx_msda.h (device pointers, enqueue-only, 0 / <0).
+ *
+ * dfx_gemm_splitk_f32: the same product for problems with few output tiles and a long K (RCNNHead's
+ * out_layer 12544 -> 256 over 300 rows per frame, /root/reference/models/sparse_roi_head/head.py:127-172):
+ * K is cut into ``splits`` ranges of whole 16-deep steps that run as independent workgroups writing partial
+ * [M,N] slabs to ``workspace`` (splits * M * N floats, caller-owned), followed by one reduction launch that
+ * adds the slabs, bias, residual and applies the activation.  Row-major A [M,K], C [M,N]; N % 4 == 0.
  */
 #ifndef DFX_GEMM_H
 #define DFX_GEMM_H
@@ -45,6 +53,11 @@ int dfx_gemm_f32(const float *A, const float *A2, long lda, long strideA,
                  float *C, long ldc, long strideC,
                  int M, int N, int K, int batch, int relu,
                  int c_block, long c_block_stride, long a_block_stride, void *stream);
+
+int dfx_gemm_splitk_f32(const float *A, long lda, const float *B, long ldb, int b_is_kn,
+                        const float *bias, int bias_per_row, const float *R, long ldr,
+                        float *C, long ldc, int M, int N, int K, int act, int splits,
+                        float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -171,3 +171,57 @@ def test_dynamic_conv_matches_module(K, R):
         got = ops.dynamic_conv(feats, params, n1, n2)
     assert got.shape == want.shape
     assert torch.allclose(got, want, rtol=2e-4, atol=2e-4), (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(2400, 256, 12544), (1200, 256, 12544), (300, 256, 4100), (77, 64, 2048)])
+def test_linear_split_k_matches_fp64(M, N, K):
+    """Few output tiles and a long K (RCNNHead.out_layer): ops.linear cuts K into ranges + one reduction launch."""
+    from dfx import ops
+    assert ops._split_k(M, N, K) > 1
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    got = ops.linear(x, w, b, relu=True, residual=res)
+    want = _ref_linear(x, w, b, True, res, None, None)
+    assert (got.double() - want).abs().max().item() < 4e-6 * K ** 0.5
+
+
+def test_linear_gelu_epilogue():
+    from dfx import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4200, 256, generator=g).cuda()
+    w = (torch.randn(256, 256, generator=g) / 16).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    want = torch.nn.functional.gelu(x.double() @ w.double().t() + b.double())
+    assert (ops.linear(x, w, b, act="gelu").double() - want).abs().max().item() < 1e-5
+
+
+def test_fused_linear_module_routes_to_the_gemm_and_keeps_state_dict_keys():
+    from models.fused import Linear
+    lin = Linear(256, 3).cuda()
+    assert list(lin.state_dict()) == ["weight", "bias"]
+    x = torch.randn(2, 300, 256).cuda()
+    with torch.no_grad():
+        got = lin(x)
+    want = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    assert got.shape == (2, 300, 3) and (got.double() - want).abs().max().item() < 1e-5
+    assert lin(x).requires_grad          # grad mode: plain nn.Linear
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 50, 84), (3, 256, 13, 21), (1, 64, 7, 5)])
+def test_group_norm_matches_torch(N, C, H, W):
+    from dfx import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 3 + 1.5).cuda()
+    gn = torch.nn.GroupNorm(32, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g))
+        gn.bias.copy_(torch.randn(C, generator=g))
+        want = torch.nn.functional.group_norm(x.double(), 32, gn.weight.double(), gn.bias.double(), gn.eps)
+        a = ops.group_norm(x, gn)
+        b = ops.group_norm(x, gn, tokens_out=True)
+    assert (a.double() - want).abs().max().item() < 2e-5
+    assert b.shape == x.shape and torch.equal(b.contiguous(), a)
+    assert b.flatten(2).transpose(1, 2).is_contiguous()       # what the transformer does next is free
