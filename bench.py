@@ -12,20 +12,31 @@ its frames are sharded in contiguous blocks over the N ranks (strong scaling): o
 one RCCL all-gather of the per-frame reference query sets per step.  A step = the whole clip.
 Inputs are resident in HBM before the timed region.  Compute type fp32 throughout.
 
+Every MSDeformAttn's sampling_offsets.weight (zero at initialisation, so that all queries would share one offset
+pattern) gets a fixed seeded perturbation N(0, 0.13^2): offsets then vary by ~2-3 pixels from query to query, the
+access pattern of a trained checkpoint, on the GPU model and the CPU baseline alike.
+
 The JSON line also carries
-  roofline     the MSDA forward kernel at the encoder geometry (csrc/msda_level.hip; N = frames per
-               micro-batch = the rank's frames by default, Lq = S = 4200, L = 1): algorithmic bytes
-               4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per launch over the mean kernel duration of those
-               launches inside the timed steps, taken from HIP events that the launch itself stamps on
-               its stream (hipExtLaunchKernelGGL); peak = 8 TB/s HBM3E (MI355X_MICROARCH.md).  With the
-               two-stream schedule active (several micro-batches per rank, --overlap 1) the kernel shares
-               the CUs with the other stream in the timed region, so the durations come from one extra
-               single-stream step after it and both averages are reported.
+  roofline     the kernel family with the largest share of GPU time in the timed steps - the fp32 MFMA GEMM
+               (csrc/gemm_f32.hip: every 1x1 convolution and Linear): sum of 2*M*N*K flops over its launches /
+               sum of their durations, against the dense fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md).
+               Durations are HIP events that each launch stamps on its own stream (hipExtLaunchKernelGGL) inside
+               the timed region.
+  roofline_kernels  the same for every stamped family with its share of the step: GEMM by operand form, the fused
+               Winograd convolution (executed MFMA flops; the direct form's flops are 2.25x as many), the
+               implicit-GEMM convolution, and the MSDA forward kernel at the encoder geometry (csrc/msda_level.hip;
+               HBM-bound: algorithmic bytes 4*(N*S*256 + 3*N*Lq*8*4 + N*Lq*256) per launch against 8 TB/s, PMC
+               traffic from profiles/).  With the two-stream schedule or the clip pipeline active the kernels share
+               the CUs with the other stream, so the durations come from one extra single-stream step.
   cpu_baseline (rank 0, N=1 only) the same path - this repository's host code on CPU tensors with
                the CPU oracle standing in for the two HIP operators - timed on a bounded sample
-               (one 12-frame clip at full resolution, ~12 s) on the box's host cores; the same clip then
-               goes through the HIP path and the differences are reported (`check_vs_hip_path`: the
-               oracle as checker at 800x1333, where the unit tests use small images).
+               (one 12-frame clip at full resolution, R = 11 reference frames per output, ~12 s) on the box's
+               host cores; the same clip then goes through the HIP path and the differences are reported
+               (`check_vs_hip_path`: floating outputs, PostProcess labels / box indices and the ordered temporal
+               top-k picks compared index by index outside a 2e-5 score tie margin - the oracle as checker at
+               800x1333, where the unit tests use small images).
+  ms_per_step_p50  median GPU time of a step from HIP events recorded between the steps (no host sync inside
+               the timed region).
 """
 import argparse
 import json
@@ -56,13 +67,22 @@ BYTES_PER_FRAME = 4.333e9
 FLOPS_PER_FRAME = 343.3e9
 HBM_PEAK = 8.0e12
 FP32_MFMA_PEAK = 157.3e12
+OFFSET_PERTURBATION = 0.13
+TIE_MARGIN = 2e-5
 
 
 def build(device, num_ref_frames):
     from models import build_model
     from models.config import transvodpp_args
+    from models.ops.modules import MSDeformAttn
     torch.manual_seed(42)
     model, _, _ = build_model(transvodpp_args("LateFusion", num_ref_frames=num_ref_frames, device=str(device)))
+    g = torch.Generator().manual_seed(4242)
+    with torch.no_grad():                     # per-query sampling offsets like a trained checkpoint's (see docstring)
+        for mod in model.modules():
+            if isinstance(mod, MSDeformAttn):
+                w = mod.sampling_offsets.weight
+                w.add_((torch.randn(w.shape, generator=g) * OFFSET_PERTURBATION).to(w.device))
     return model.to(device).eval()
 
 
@@ -95,13 +115,36 @@ def cpu_baseline(height, width, threads, frames=12):
     finally:
         f.MSDeformAttnFunction, ops.roi_align = saved
     line = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"one {frames}-frame clip at {height}x{width}, all-current mode, {dt:.1f} s of CPU work, "
-                      "torch CPU ops + oracle/msda_oracle.c for MSDA and RoIAlign"}
+            "sample": f"one {frames}-frame clip at {height}x{width}, all-current mode (R = {frames - 1} reference frames per "
+                      f"output; the GPU line runs R = 31), {dt:.1f} s of CPU work, torch CPU ops + oracle/msda_oracle.c for "
+                      "MSDA and RoIAlign"}
     # the same clip through the HIP path (same seed -> same weights): the checker role of the oracle, at full resolution
     got = ClipRunner(build(torch.device("cuda", torch.cuda.current_device()), frames - 1), micro_batch=frames)(clip.cuda())
+    from models.detector_common import PostProcess
+    sizes = torch.as_tensor([[height, width]] * frames)
+    pp_g, pp_c = PostProcess()({k: got[k].cpu() for k in ("pred_logits", "pred_boxes")}, sizes), PostProcess()(want, sizes)
+    C = want["pred_logits"].shape[-1]
+
+    def clear_ranks(ref_scores):                 # ranks whose reference score is separated from both neighbours
+        gap = (ref_scores[:, :-1] - ref_scores[:, 1:]).abs()
+        inf = torch.full_like(ref_scores[:, :1], float("inf"))
+        return (torch.cat([inf, gap], 1) > TIE_MARGIN) & (torch.cat([gap, inf], 1) > TIE_MARGIN)
+
+    def ordered(ref_idx, got_idx, ref_scores):
+        clear = clear_ranks(ref_scores)
+        return {"ranks_compared": int(clear.sum()), "of": ref_idx.numel(),
+                "mismatches": int((ref_idx[clear] != got_idx[clear]).sum())}
+
+    sc = torch.stack([r["scores"] for r in pp_c])
+    idx_c = torch.topk(want["pred_logits"].sigmoid().flatten(1), 100, dim=1)[1]
+    idx_g = torch.topk(got["pred_logits"].cpu().sigmoid().flatten(1), 100, dim=1)[1]
     line["check_vs_hip_path"] = {
         "max_abs_diff_pred_logits": float((got["pred_logits"].cpu() - want["pred_logits"]).abs().max()),
         "max_abs_diff_pred_boxes": float((got["pred_boxes"].cpu() - want["pred_boxes"]).abs().max()),
+        "tie_margin": TIE_MARGIN,
+        "postprocess_box_idx": ordered(idx_c // C, idx_g // C, sc),
+        "postprocess_labels": ordered(torch.stack([r["labels"] for r in pp_c]), torch.stack([r["labels"] for r in pp_g]), sc),
+        "temporal_topk_ordered": [ordered(pc, pg.cpu(), vc) for pg, pc, vc in zip(got["topk"], want["topk"], want["topk_scores"])],
         "temporal_topk_sets_equal": all(set(a.tolist()) == set(b.tolist())
                                         for pg, pc in zip(got["topk"], want["topk"]) for a, b in zip(pg.cpu(), pc))}
     return line
@@ -180,13 +223,17 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    ops.profile_start()                                            # MSDA kernels stamp their own begin/end events
+    ops.profile_start()                                            # kernels stamp their own begin/end events
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         step()
+        marks[i + 1].record()                                      # on the current stream: no host sync
     barrier()
     dt = time.perf_counter() - t0
     launches = ops.profile_stop()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     timed_region_launches = None
     if overlapped or pipelined:
         # In the timed region the MSDA kernel shares the CUs with the other stream's convolutions, so
@@ -209,27 +256,59 @@ def main():
 
     if rank == 0:
         fps = a.frames * a.steps / dt
-        enc = [(sec, nbytes) for (sec, nbytes, lq, s) in launches if lq == s and sec > 0]
+        steps_profiled = a.steps if timed_region_launches is None else 1
+        step_s = dt / a.steps
+        fam = {-1: ("gemm_f32_kernel, [K,N] operand (1x1 convolutions of the backbones / input_proj)", "mfma"),
+               -2: ("gemm_f32_kernel, [N,K] operand (Linear layers)", "mfma"),
+               -3: ("conv_wino_kernel (3x3 stride-1 convolutions, Winograd F(2x2,3x3); executed MFMA flops, the direct "
+                    "form has 2.25x as many)", "mfma"),
+               -4: ("conv_igemm_kernel (7x7/2 stem, 3x3/2, DFormer stem)", "mfma")}
+        kernels = []
+        for tag, (name, bound) in fam.items():
+            rec = [(sec, work) for (sec, work, ta, tb) in launches if ta == tag and sec > 0]
+            if not rec:
+                continue
+            tsum, wsum = sum(x for x, _ in rec), sum(w for _, w in rec)
+            kernels.append({"kernel": name, "bound": bound, "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12,
+                            "unit": "TFLOP/s", "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": None,
+                            "launches_per_step": round(len(rec) / steps_profiled, 1),
+                            "flops_per_step": wsum / steps_profiled, "ms_per_step": round(tsum / steps_profiled * 1e3, 3),
+                            "share_of_step": round(tsum / steps_profiled / step_s, 4)})
+        gemm = [(sec, work) for (sec, work, ta, tb) in launches if ta in (-1, -2) and sec > 0]
         roof = None
+        if gemm:
+            tsum, wsum = sum(x for x, _ in gemm), sum(w for _, w in gemm)
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA GEMM: every 1x1 convolution and Linear; the family "
+                                               "with the largest share of GPU time)",
+                    "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": None,
+                    "launches": len(gemm), "flops_per_launch": wsum / len(gemm), "avg_launch_us": round(tsum / len(gemm) * 1e6, 2),
+                    "share_of_step": round(tsum / steps_profiled / step_s, 4),
+                    "measured": "HIP events stamped by each launch, timed region; achieved = sum of 2*M*N*K / sum of durations"}
+        enc = [(sec, nbytes) for (sec, nbytes, lq, s) in launches if lq > 0 and lq == s and sec > 0]
         if enc:
             mean_t = sum(x for x, _ in enc) / len(enc)
             nbytes = enc[0][1]
-            roof = {"bound": "hbm", "kernel": "msda_fused_level<2> (encoder / late-fusion geometry, level in LDS)",
-                    "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            msda = {"kernel": "msda_fused_level<2> (MSDA forward, encoder / late-fusion geometry, level in LDS, per-query offsets)",
+                    "bound": "hbm", "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
                     "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, per_rank)),
                     "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_msda_level_N8.md",
-                    "launches": len(enc), "bytes_per_launch": nbytes, "avg_launch_us": round(mean_t * 1e6, 2),
-                    "measured": "HIP events stamped by the launch, timed region"}
+                    "launches_per_step": round(len(enc) / steps_profiled, 1), "bytes_per_launch": nbytes,
+                    "avg_launch_us": round(mean_t * 1e6, 2),
+                    "share_of_step": round(mean_t * len(enc) / steps_profiled / step_s, 4)}
             if timed_region_launches is not None:
-                shared = [sec for (sec, _, lq, s) in timed_region_launches if lq == s and sec > 0]
-                roof["measured"] = ("HIP events stamped by the launch, one extra single-stream step after the timed "
-                                    "region (two-stream schedule / clip pipeline off)")
-                roof["avg_launch_us_timed_region_shared_cus"] = round(sum(shared) / max(len(shared), 1) * 1e6, 2)
+                shared = [sec for (sec, _, lq, s) in timed_region_launches if lq > 0 and lq == s and sec > 0]
+                msda["avg_launch_us_timed_region_shared_cus"] = round(sum(shared) / max(len(shared), 1) * 1e6, 2)
+            kernels.append(msda)
+        if roof is not None and timed_region_launches is not None:
+            roof["measured"] = ("HIP events stamped by each launch, one extra single-stream step after the timed region "
+                                "(two-stream schedule / clip pipeline off)")
         line = {
             "metric": "frames/sec at 800x1333 RGB-D, TransVOD++ Late-Fusion", "value": round(fps, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(step_ms[len(step_ms) // 2], 3),
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TransVOD++ LateFusion, {a.frames}-frame {a.height}x{a.width} RGB-D clip, "
                                    f"all-current mode (R={a.frames - 1}), L=1 DC5 (S=4200), 300 queries, 3 classes",
@@ -237,6 +316,7 @@ def main():
                        "parallelism": f"frame-shard x{world} + 1 all-gather/clip",
                        "two_stream_overlap": overlapped, "clip_pipeline": pipelined},
             "roofline": roof,
+            "roofline_kernels": kernels,
             "e2e": {"hbm_frac": round(fps / world * BYTES_PER_FRAME / HBM_PEAK, 4),
                     "fp32_mfma_frac": round(fps / world * FLOPS_PER_FRAME / FP32_MFMA_PEAK, 4),
                     "bytes_per_frame": BYTES_PER_FRAME, "flops_per_frame": FLOPS_PER_FRAME},

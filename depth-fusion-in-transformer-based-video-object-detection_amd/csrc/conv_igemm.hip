@@ -168,7 +168,8 @@ template <int BM, int WM, int WN>
 int launch(const IgemmArgs &g, int N, hipStream_t st)
 {
     const dim3 grid((g.Ho * g.Wo + 127) / 128, (g.Co + BM - 1) / BM, N), block(256);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, WM, WN>), grid, block, 0, st, g);
+    // measurement aid (dfx_profile_*): flops of the launch (K padding included) in the byte field, tag_a = -4
+    dfx::launch_timed(2L * g.Co * g.Kpad * g.Ho * g.Wo * N, -4, BM, conv_igemm_kernel<BM, WM, WN>, grid, block, 0, st, g);
     return dfx::check_launch("conv_igemm_kernel");
 }
 

@@ -308,7 +308,10 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     const long blocks = ntb * (Co / kCoB);
     if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "conv3x3_wino: grid too large");
     g.ntb = (int)ntb;
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks), dim3(512), 0, static_cast<hipStream_t>(stream), g);
+    // measurement aid (dfx_profile_*): MFMA flops the launch executes (16 products per 2x2 output tile, padded tiles
+    // included) in the byte field, tag_a = -3, tag_b = dilation; the direct form's flops are 2.25x as many
+    dfx::launch_timed(2L * 16 * Co * Ci * g.tiles, -3, dilation, conv_wino_kernel, dim3((unsigned)blocks), dim3(512), 0,
+                      static_cast<hipStream_t>(stream), g);
     return dfx::check_launch("conv_wino_kernel");
 }
 

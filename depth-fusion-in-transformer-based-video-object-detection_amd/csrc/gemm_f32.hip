@@ -314,10 +314,13 @@ template <int BM, int BN, int WM, int WN, int BK = 16>
 int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
 {
     const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * (g.splits > 1 ? g.splits : 1)), block(256);
+    // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
+    // or -2 (Linear), tag_b = tile
+    const long flops = 2L * g.M * g.N * g.K * batch;
     if (b_is_kn)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, BK>), grid, block, 0, st, g);
+        dfx::launch_timed(flops, -1, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, true, BK>, grid, block, 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, BK>), grid, block, 0, st, g);
+        dfx::launch_timed(flops, -2, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, false, BK>, grid, block, 0, st, g);
     return dfx::check_launch("gemm_f32_kernel");
 }
 

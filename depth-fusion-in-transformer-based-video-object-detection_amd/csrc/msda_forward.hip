@@ -323,7 +323,7 @@ extern "C" int dfx_msda_forward_f64(const double *value, const int64_t *shapes, 
     return dfx::check_launch("msda_fwd_generic<double>");
 }
 
-extern "C" int dfx_abi_version(void) { return 2; }
+extern "C" int dfx_abi_version(void) { return 3; }
 
 extern "C" int dfx_profile_enable(int on)
 {

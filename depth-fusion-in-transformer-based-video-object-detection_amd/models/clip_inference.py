@@ -189,7 +189,8 @@ class ClipRunner:
             local["spatial_shapes"], local["level_start_index"], local["valid_ratios"],
             m.temp_class_embed_list, m.temp_bbox_embed_list)
         return {"pred_logits": m.temp_class_embed_list[2](final_hs),
-                "pred_boxes": apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs), "topk": picks}
+                "pred_boxes": apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs), "topk": picks,
+                "topk_scores": tr.last_pick_scores}
 
     @torch.no_grad()
     def __call__(self, frames, mask=None):

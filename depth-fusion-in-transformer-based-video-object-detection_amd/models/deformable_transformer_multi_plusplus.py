@@ -136,11 +136,12 @@ class DeformableTransformer(SpatialTransformerBase):
         for attr in ("_dfx_host", "_dfx_tokens"):
             if hasattr(spatial_shapes, attr) and spatial_shapes.shape[0] == 1:
                 setattr(shapes1, attr, getattr(spatial_shapes, attr))
-        aux, picks = [], []
+        aux, picks, pick_scores = [], [], []
         final_hs, final_refs = cur_hs, cur_reference_out
         for i, k in enumerate(TOPK_PER_REF):
-            idx = torch.topk(score, k * R, dim=1)[1]                               # [F,kR] in [0, R*Q)
+            vals, idx = torch.topk(score, k * R, dim=1)                             # [F,kR] in [0, R*Q)
             picks.append(idx)
+            pick_scores.append(vals)
             rows = torch.gather(others, 1, idx // Q) * Q + idx % Q                 # rows of the flat pool
             selected = flat_pool[rows.reshape(-1)].view(F_, k * R, C)
             cur_hs = getattr(self, f"temporal_query_layer{i + 1}")(cur_hs, selected)
@@ -151,6 +152,7 @@ class DeformableTransformer(SpatialTransformerBase):
                             "pred_boxes": apply_box_head(temp_bbox_embed_list[i], cur_hs, refs)})
             else:
                 final_hs, final_refs = cur_hs, refs
+        self.last_pick_scores = pick_scores            # the scores of the picks (parity checks compare outside ties)
         return final_hs, final_refs, aux, picks
 
     # ------------------------------------------------------------------------------------------

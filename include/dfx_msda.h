@@ -52,11 +52,15 @@ const char *dfx_last_error(void);
 
 /*
  * Measurement aid (bench.py); not part of the reference's surface and the one place with process-wide
- * state.  While enabled, every fused MSDA kernel is dispatched with hipExtLaunchKernelGGL, which stamps
- * an event pair with the kernel's own begin / end timestamps (the kernel duration proper, on the launch
- * stream, without the dispatch gap of hipEventRecord pairs).  dfx_profile_drain waits for the recorded
- * kernels, writes up to `cap` records (duration in ms, algorithmic bytes of the launch, Lq, S), frees the
- * events and returns the number written.
+ * state.  While enabled, every fused MSDA kernel, every GEMM and every convolution launch is dispatched with
+ * hipExtLaunchKernelGGL, which stamps an event pair with the kernel's own begin / end timestamps (the kernel
+ * duration proper, on the launch stream, without the dispatch gap of hipEventRecord pairs).
+ * dfx_profile_drain waits for the recorded kernels, writes up to `cap` records, frees the events and returns
+ * the number written.  Record = (duration in ms, work, tag_a, tag_b):
+ *   MSDA kernels      work = algorithmic bytes of the launch, tag_a = Lq (> 0), tag_b = S
+ *   gemm_f32_kernel   work = 2*M*N*K*batch flops, tag_a = -1 ([K,N] operand: 1x1 convolution) / -2 (Linear), tag_b = tile
+ *   conv_wino_kernel  work = MFMA flops executed (2*16*Co*Ci per 2x2 tile), tag_a = -3, tag_b = dilation
+ *   conv_igemm_kernel work = 2*Co*Kpad*Ho*Wo*N flops, tag_a = -4, tag_b = tile rows
  */
 int dfx_profile_enable(int on);
 int dfx_profile_drain(float *ms, long *bytes, int *lq, int *s, int cap);

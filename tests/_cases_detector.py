@@ -1,0 +1,158 @@
+"""Shared recipes for the DETECTOR-level golden vectors.
+
+``run_detector_cases(ns)`` builds the single-frame Deformable-DETR (Late Fusion) and the TransVOD++ detector
+(Late Fusion) from the module namespace ``ns`` around STUB backbones that return seeded feature maps (the real
+backbones need torchvision / pretrained downloads on the reference side), fills every parameter by
+state_dict name (tests/_param_fill.py), runs ``model(NestedTensor)`` and the post-processing the caller applies:
+
+  * ``pred_logits`` / ``pred_boxes`` / ``aux_outputs``                       (deformable_detr_single.py:204-362,
+                                                                              deformable_detr_multi_plusplus.py:210-342)
+  * ``PostProcess`` scores / labels / boxes and the implied box indices       (deformable_detr_single.py:569-603)
+  * the inference filter ``softmax(-1)[0][:, 1] > keep_prob``                 (inference.py:918-930)
+  * every ``torch.topk`` call the forward makes (values + int64 indices, in call order): the temporal stage's
+    ordered picks of k*R reference queries                                    (deformable_transformer_multi_plusplus.py:529,554,576)
+
+tools/gen_golden_detector.py runs it with the REFERENCE's classes and stores tests/golden/detector.npz;
+tests/test_detector_golden.py (CPU, oracle operators) and tests/test_models_gpu.py (HIP kernels) run it with this
+repository's classes.  ``ns``: single, multipp (detector modules: DeformableDETR, PostProcess), ts, tpp
+(transformer modules), NestedTensor, NestedTensorMulti (util.misc_multi), PositionEmbeddingSine.
+"""
+import torch
+from torch import nn
+
+from tests._param_fill import fill_params_by_name
+
+KEEP_PROB = 0.3
+
+
+def _rnd(seed, *shape, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+class StubJoiner(nn.Module):
+    """Stands where Joiner(backbone, position_embedding) stands: ``self(samples) -> (features, pos, None, None)``
+    (the fusion-backbone call shape, backbone_scratch.py:168-187) with one seeded stride-32 feature map; ``self[1]`` is
+    the positional encoding (used by the detectors for extra levels)."""
+
+    strides = [32]
+    name = "resnet50"
+    d_name = "dformer"
+
+    def __init__(self, pos, NestedTensor, channels, seed, depth=False):
+        super().__init__()
+        self.pos, self.NT, self.channels, self.seed, self.depth = pos, NestedTensor, channels, seed, depth
+        self.num_channels = [channels]
+
+    def __getitem__(self, i):
+        return (self, self.pos)[i]
+
+    def forward(self, samples):
+        x, m = samples.tensors, samples.mask
+        h, w = -(-x.shape[2] // 32), -(-x.shape[3] // 32)
+        feat = _rnd(self.seed, x.shape[0], self.channels, h, w).relu().to(x.device)
+        mask = torch.nn.functional.interpolate(m[None].float(), size=(h, w)).to(torch.bool)[0]
+        nt = self.NT(feat, mask)
+        pos = [self.pos(nt).to(feat.dtype)]
+        return ([nt], pos) if self.depth else ([nt], pos, None, None)
+
+
+class TopkRecorder:
+    """Records every torch.topk call made inside the ``with`` block (values, indices)."""
+
+    def __enter__(self):
+        self.calls, self._orig = [], torch.topk
+
+        def topk(*a, **k):
+            out = self._orig(*a, **k)
+            self.calls.append((out[0].detach().cpu().clone(), out[1].detach().cpu().clone()))
+            return out
+
+        torch.topk = topk
+        return self
+
+    def __exit__(self, *exc):
+        torch.topk = self._orig
+
+
+def run_detector_cases(ns, device="cpu"):
+    NestedTensor, PE = ns.NestedTensor, ns.PositionEmbeddingSine
+    NTM = getattr(ns, "NestedTensorMulti", NestedTensor)     # util.misc_multi's own NestedTensor class
+    blobs = {}
+
+    def put(case, **tensors):
+        for k, v in tensors.items():
+            blobs[f"{case}.{k}"] = v.detach().cpu()
+
+    def post(case, det_mod, out, sizes):
+        res = det_mod.PostProcess()(out, sizes)
+        logits = out["pred_logits"]
+        # the indices PostProcess gathers the boxes with (it does not return them): same rule, same call
+        idx = torch.topk(logits.sigmoid().view(logits.shape[0], -1), 100, dim=1)[1]
+        put(case, pp_scores=torch.stack([r["scores"] for r in res]), pp_labels=torch.stack([r["labels"] for r in res]),
+            pp_boxes=torch.stack([r["boxes"] for r in res]), pp_box_idx=idx // logits.shape[2])
+        probas = logits.softmax(-1)[0]
+        put(case, keep_probas=probas[:, 1], keep_mask=probas[:, 1] > KEEP_PROB)
+
+    dtype_str = "DepthDeform_latefusion_dformer"
+    H, W = 160, 256                                        # stride-32 map: 5 x 8
+
+    def masks(n):
+        m = torch.zeros(n, H, W, dtype=torch.bool)
+        if n > 1:
+            m[1, :, 200:] = True                           # frame 1 is padded on the right
+        return m.to(device)
+
+    # ---- single-frame Deformable-DETR + Late Fusion (a16, a18) ---------------------------------------------
+    B, Q = 2, 120
+    tr = ns.ts.DeformableTransformer(d_model=256, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                     dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=True,
+                                     num_feature_levels=1, dec_n_points=4, enc_n_points=4, two_stage=False,
+                                     two_stage_num_proposals=Q, use_depth=True, depth_type=dtype_str, dpth_n_points=4)
+    pe = PE(128, normalize=True)
+    det = ns.single.DeformableDETR(StubJoiner(pe, NestedTensor, 2048, 301), StubJoiner(pe, NestedTensor, 128, 302, depth=True),
+                                   tr, num_classes=3, num_queries=Q, num_feature_levels=1, aux_loss=True,
+                                   with_box_refine=True, two_stage=False, use_depth=True, depth_type=dtype_str).eval()
+    fill_params_by_name(det, seed=41)
+    det = det.to(device)
+    x = _rnd(303, B, 4, H, W).to(device)
+    with TopkRecorder():
+        out = det(NestedTensor(x, masks(B)))
+    put("det_single", pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"],
+        aux0_logits=out["aux_outputs"][0]["pred_logits"], aux0_boxes=out["aux_outputs"][0]["pred_boxes"])
+    post("det_single", ns.single, out, torch.as_tensor([[480, 640], [300, 400]], device=device))
+
+    # ---- TransVOD++ + Late Fusion: clip of 1 + R frames, output for frame 0 (a16, a11, a18) ------------------
+    R, Q = 2, 90
+    tr = ns.tpp.DeformableTransformer(d_model=256, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                      dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=True,
+                                      num_feature_levels=1, dec_n_points=4, enc_n_points=4, two_stage=False,
+                                      two_stage_num_proposals=Q, num_query=Q, n_temporal_decoder_layers=1,
+                                      num_ref_frames=R, fixed_pretrained_model=False, args=None, use_depth=True,
+                                      depth_type=dtype_str, dpth_n_points=4)
+    det = ns.multipp.DeformableDETR(StubJoiner(pe, NTM, 2048, 311), StubJoiner(pe, NTM, 128, 312, depth=True),
+                                    tr, num_classes=3, num_queries=Q, num_feature_levels=1, num_ref_frames=R,
+                                    aux_loss=True, with_box_refine=True, two_stage=False, use_depth=True,
+                                    depth_type=dtype_str).eval()
+    fill_params_by_name(det, seed=51)
+    det = det.to(device)
+    x = _rnd(313, R + 1, 4, H, W).to(device)
+    with TopkRecorder() as rec:
+        out = det(NTM(x, torch.zeros(R + 1, H, W, dtype=torch.bool, device=device)))
+    put("det_multipp", pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"],
+        aux0_logits=out["aux_outputs"][0]["pred_logits"], aux1_boxes=out["aux_outputs"][1]["pred_boxes"])
+    assert len(rec.calls) == 3, "the temporal stage makes three top-k picks"
+    for i, (vals, idx) in enumerate(rec.calls):
+        put("det_multipp", **{f"topk{i}_values": vals, f"topk{i}_idx": idx})
+    post("det_multipp", ns.multipp, out, torch.as_tensor([[480, 640]], device=device))
+    return blobs
+
+
+def compare_indices(ref_idx, got_idx, ref_scores, margin):
+    """Ordered index tensors [B,k] from a top-k: equal wherever the reference score at that rank is separated from its
+    neighbours by more than ``margin`` (ties and near-ties may legitimately swap under fp32 rounding differences).
+    Returns (number compared, number of mismatches among them)."""
+    s = ref_scores
+    gap_prev = torch.cat([torch.full_like(s[:, :1], float("inf")), (s[:, :-1] - s[:, 1:]).abs()], 1)
+    gap_next = torch.cat([(s[:, :-1] - s[:, 1:]).abs(), torch.full_like(s[:, :1], float("inf"))], 1)
+    clear = (gap_prev > margin) & (gap_next > margin)
+    return int(clear.sum()), int((ref_idx[clear] != got_idx[clear]).sum())
