@@ -156,12 +156,24 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         }
     };
 
+    // Two waves share a SIMD (wave w and w + 4).  Their staging work is phase-shifted so that the matrix pipe always has
+    // a wave in its MFMA block: waves 0-3 ("early") load chunk t+1 before their MFMAs of chunk t and transform / store it
+    // after them; waves 4-7 ("late") transform / store chunk t+1 - loaded one iteration earlier - BEFORE their MFMAs of
+    // chunk t, then load chunk t+2.  Either way chunk t+1 is complete at the barrier that ends iteration t, and the
+    // buffer it goes to (that of chunk t-1) was released by the previous barrier.
+    const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
     load_chunk(0);
     store_chunk(0);
+    if (late && g.nchunk > 1) load_chunk(1);
     __syncthreads();
     for (int ch = 0; ch < g.nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < g.nchunk) load_chunk(ch + 1);       // in flight during the MFMAs below
+        if (!late) {
+            if (ch + 1 < g.nchunk) load_chunk(ch + 1);   // in flight during the MFMAs below
+        } else {
+            if (ch + 1 < g.nchunk) store_chunk(buf ^ 1);
+            if (ch + 2 < g.nchunk) load_chunk(ch + 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // operand fragments of both positions up front: the second position's LDS reads complete under the
         // first position's MFMAs
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ch + 1 < g.nchunk) store_chunk(buf ^ 1);
+        if (!late && ch + 1 < g.nchunk) store_chunk(buf ^ 1);
         __syncthreads();
     }
 

@@ -377,12 +377,16 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
     if (N <= 64) return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
     if (N <= 96) return launch<128, 96, 4, 1>(g, batch, b_is_kn, st);
-    // Measured on the path's shapes (tools/bench_gemm.py with DFX_GEMM_TILE): all tiles land within
-    // ~10 % of each other (the kernel is paced by the matrix pipe at the clock the chip holds, not by
-    // operand reuse), and the 64 x 128 tile - 6 waves per SIMD - is the most even performer; the
-    // 128 x 128 tile is kept for the large, deep convolutions of layer4 where it is 2-3 % ahead.
-    if (M >= 1024 && (long)N * batch >= 16384 && K >= 512 && K <= 1024) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
-    if (K >= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) * zb >= 8 * 768) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    // Measured on the path's shapes at 32 frames (tools/bench_gemm.py with DFX_GEMM_TILE, profiles/r02_bench_gemm_tiles.txt):
+    // the 128 x 128 tile (half the operand traffic per flop) is 2-6 % ahead wherever it still gives every CU several
+    // tiles and K is deep enough to amortise its longer prologue / epilogue; a short K with a residual epilogue
+    // (Bottleneck.conv3 of layer2 / layer3) and M = 64 (layer1) stay on 64 x 128 (6 waves per SIMD).
+    {
+        const long t128x128 = (long)((M + 127) / 128) * ((N + 127) / 128) * zb;
+        const bool rows_fit = (M % 128 == 0) || M >= 1024;
+        if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 512)))
+            return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+    }
     // Few tiles (token GEMMs of a 4- or 8-frame rank block): all workgroups are resident at once, the CUs that get
     // one tile more than the others set the time.  A 64 x 64 tile halves that quantum (M = 16800, N = 256:
     // 526 tiles of 64 x 128 = 3 on some CUs, 2.05 on average; 1052 of 64 x 64 = 5 against 4.1).
