@@ -22,14 +22,16 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct IgemmArgs {
     const float *X, *Wp;
-    const int *ktab;
+    const int2 *ktab;          // per k: {tap index ky*KW+kx (or -1: padding column), byte offset ci*H*W*4 + (ky*dil*W + kx*dil)*4}
     const float *bias;
     float *Y;
-    int Ci, H, W, Co, Ho, Wo, Kpad, stride, pad, act;
+    int Ci, H, W, Co, Ho, Wo, Kpad, stride, pad, act, KH, KW, dil;
     long strideX, strideY;
+    int wide;                  // Ho*Wo % 4 == 0 and y 16-byte aligned: float4 epilogue through LDS
 };
 
 __device__ __forceinline__ float activate(float v, int act)
@@ -44,29 +46,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
 {
     constexpr int BN = 128, BK = 16;
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
-    constexpr int LDK = BK + 4, LDB = BN + 4;
+    constexpr int LDK = BK + 4, LDB = BN + 4, LDC = BN + 4;
     constexpr int A_F4 = BM * BK / 4, A_LOADS = (A_F4 + 255) / 256;
     constexpr int B_ROWS = BK / 2;                     // k rows per thread per K-step
+    constexpr int A_SZ = BM * LDK, B_SZ = BK * LDB, C_SZ = 64 * LDC;
+    constexpr int S_SZ = 2 * (A_SZ + B_SZ) > C_SZ ? 2 * (A_SZ + B_SZ) : C_SZ;
     static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad wave layout");
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    __shared__ __attribute__((aligned(16))) float smem[S_SZ];
+    float (*const As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(smem);
+    float (*const Bs)[B_SZ] = reinterpret_cast<float (*)[B_SZ]>(smem + 2 * A_SZ);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, c = lane & 31;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const long bz = blockIdx.z;
-    const float *X = g.X + bz * g.strideX;
     const int P = g.Ho * g.Wo, HW = g.H * g.W;
 
-    // this thread's output pixel and the top-left input pixel of its receptive field
+    // this thread's output pixel, the top-left input pixel of its receptive field, and a bit per tap that lies
+    // inside the map (KH*KW <= 64)
     const int pl = tid & (BN - 1);
     const int kb = __builtin_amdgcn_readfirstlane(tid >> 7);        // 0 / 1: wave-uniform
     const int p = n0 + pl;
     const bool pv = p < P;
     const int oy = (pv ? p : 0) / g.Wo, ox = (pv ? p : 0) - oy * g.Wo;
     const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
-    const int pbase = iy0 * g.W + ix0;
+    unsigned long long taps = 0;
+    if (pv) {
+        unsigned rows = 0, cols = 0;
+        for (int ky = 0; ky < g.KH; ++ky) rows |= (unsigned)((unsigned)(iy0 + ky * g.dil) < (unsigned)g.H) << ky;
+        for (int kx = 0; kx < g.KW; ++kx) cols |= (unsigned)((unsigned)(ix0 + kx * g.dil) < (unsigned)g.W) << kx;
+        for (int ky = 0; ky < g.KH; ++ky)
+            if ((rows >> ky) & 1u) taps |= (unsigned long long)cols << (ky * g.KW);
+    }
+    // Buffer loads.  The image descriptor starts `bias_el` elements BEFORE the image, so that the per-lane offset of the
+    // receptive field's top-left corner (which lies up to pad rows / columns outside the map) is never negative; the
+    // tap's own offset is the scalar offset of the instruction.  A lane whose tap is outside the map gets an offset
+    // beyond the extent and the hardware returns 0 for it: no clamp, no select, one shift + compare per element.
+    constexpr unsigned kOut = 0x80000000u;
+    const int bias_el = g.pad * g.W + g.pad;
+    const float *Xn = g.X + bz * g.strideX - bias_el;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Xn), 0, (int)(((long)g.Ci * HW + bias_el) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.Wp), 0, (int)((long)g.Co * g.Kpad * 4), 0x00020000);
+    const unsigned vx = (unsigned)(iy0 * g.W + ix0 + bias_el) * 4u;
+    unsigned va[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int f = tid + i * 256, row = f / (BK / 4), kq = f % (BK / 4), m = m0 + row;
+        va[i] = (m < g.Co && f < A_F4) ? ((unsigned)m * (unsigned)g.Kpad + (unsigned)kq * 4u) * 4u : kOut;
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -76,26 +104,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_LOADS];
+    f32x4 ra[A_LOADS];
     float rb[B_ROWS];
-    unsigned okb = 0;
-
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * 256, row = f / (BK / 4), kq = f % (BK / 4);
-            const int mc = min(m0 + row, g.Co - 1);                  // rows past Co are never stored
-            ra[i] = *reinterpret_cast<const float4 *>(g.Wp + (long)mc * g.Kpad + k0 + kq * 4);
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, va[i], 0, 0));
+            va[i] += BK * 4u;
         }
-        okb = 0;
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
-            const int e = g.ktab[k0 + kb + 2 * i];                   // scalar load: k is wave-uniform
-            const int ci = e & 0xffff, dy = (e >> 16) & 0xff, dx = (e >> 24) & 0x7f;
-            const bool ok = pv && e >= 0 && (unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W;
-            const int off = ci * HW + dy * g.W + dx + pbase;
-            rb[i] = X[ok ? off : 0];
-            okb |= (unsigned)ok << i;
+            const int2 e = g.ktab[k0 + kb + 2 * i];                  // scalar load: k is wave-uniform
+            const bool ok = e.x >= 0 && ((taps >> (e.x & 63)) & 1ull);
+            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, ok ? vx : kOut, e.y, 0));
         }
     };
     auto store_tiles = [&](int buf) {
@@ -103,10 +124,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
         for (int i = 0; i < A_LOADS; ++i) {
             const int f = tid + i * 256, row = f / (BK / 4), kq = f % (BK / 4);
             if (f >= A_F4) continue;
-            *reinterpret_cast<float4 *>(&As[buf][row][kq * 4]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&As[buf][row][kq * 4]) = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) Bs[buf][(kb + 2 * i) * LDB + pl] = (okb >> i) & 1u ? rb[i] : 0.f;
+        for (int i = 0; i < B_ROWS; ++i) Bs[buf][(kb + 2 * i) * LDB + pl] = rb[i];
     };
 
     const int steps = g.Kpad / BK;
@@ -117,12 +138,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
         const int buf = t & 1;
         if (t + 1 < steps) load_tiles((t + 1) * BK);
         constexpr int KJ = BK / 8;
-        float4 af[KJ][MT];
+        f32x4 af[KJ][MT];
 #pragma unroll
         for (int j = 0; j < KJ; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[j][i] = *reinterpret_cast<const float4 *>(&As[buf][wm * TM + i * 32 + c][j * 8 + half * 4]);
+                af[j][i] = *reinterpret_cast<const f32x4 *>(&As[buf][wm * TM + i * 32 + c][j * 8 + half * 4]);
         float bs[2][NT];
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) bs[0][jn] = Bs[buf][(half * 4) * LDB + wn * TN + jn * 32 + c];
@@ -137,10 +158,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const float av = tt == 0 ? af[j][i].x : tt == 1 ? af[j][i].y : tt == 2 ? af[j][i].z : af[j][i].w;
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bs[cur][jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][i][tt], bs[cur][jn], acc[i][jn], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -149,6 +169,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
     }
 
     float *Y = g.Y + bz * g.strideY;
+    if (g.wide) {
+        // as gemm_f32.hip: accumulators through LDS, 64 tile rows at a time, out as float4 - whole 512-byte row segments
+        float *Ct = smem;
+#pragma unroll
+        for (int ps = 0; ps < BM / 64; ++ps) {
+            if (ps > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if ((wm * TM + i * 32) / 64 != ps) continue;
+                const int rbase = wm * TM + i * 32 - ps * 64 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        Ct[(rbase + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f0 = 0; f0 < 64 * BN / 4; f0 += 256) {
+                const int f = f0 + tid, row = f / (BN / 4), c4 = f % (BN / 4);
+                const int m = m0 + ps * 64 + row, n = n0 + c4 * 4;
+                if (m >= g.Co || n >= P) continue;
+                float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
+                const float bv = g.bias ? g.bias[m] : 0.f;
+                v.x = activate(v.x + bv, g.act); v.y = activate(v.y + bv, g.act);
+                v.z = activate(v.z + bv, g.act); v.w = activate(v.w + bv, g.act);
+                *reinterpret_cast<float4 *>(Y + (long)m * P + n) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -176,19 +227,23 @@ int launch(const IgemmArgs &g, int N, hipStream_t st)
 }  // namespace
 
 extern "C" int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const float *bias, float *y,
-                                    int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int stride,
-                                    int pad, int act, void *stream)
+                                    int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
+                                    int stride, int pad, int dilation, int act, void *stream)
 {
-    if (N < 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || Ho < 0 || Wo < 0 || Kpad <= 0 || stride <= 0 || pad < 0)
+    if (N < 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || Ho < 0 || Wo < 0 || Kpad <= 0 || stride <= 0 || pad < 0 ||
+        KH <= 0 || KW <= 0 || dilation <= 0)
         return dfx::fail(DFX_EINVAL, "conv2d_igemm: bad dimension");
     if ((long)N * Ho * Wo == 0) return DFX_OK;
     if (!x || !wp || !ktab || !y) return dfx::fail(DFX_EINVAL, "conv2d_igemm: null pointer");
     if (Kpad % 16 || !dfx::aligned16(wp)) return dfx::fail(DFX_EINVAL, "conv2d_igemm: Kpad must be a multiple of 16, wp 16-byte aligned");
-    if (Ci > 65535 || (long)Ci * H * W >= (1L << 31) || (long)Co * Ho * Wo >= (1L << 31))
-        return dfx::fail(DFX_ERANGE, "conv2d_igemm: one image's tensor exceeds 2^31 elements");
+    if (KH * KW > 64) return dfx::fail(DFX_EINVAL, "conv2d_igemm: at most 64 taps");
+    if (((long)Ci * H * W + (long)pad * W + pad) * 4 >= (1L << 31) || (long)Co * Ho * Wo >= (1L << 31) || (long)Co * Kpad * 4 >= (1L << 31))
+        return dfx::fail(DFX_ERANGE, "conv2d_igemm: one image's tensor exceeds 2 GiB");
     if (N > 65535) return dfx::fail(DFX_ERANGE, "conv2d_igemm: batch too large");
     if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "conv2d_igemm: unknown activation");
-    IgemmArgs g{x, wp, ktab, bias, y, Ci, H, W, Co, Ho, Wo, Kpad, stride, pad, act, (long)Ci * H * W, (long)Co * Ho * Wo};
+    const int wide = ((Ho * Wo) & 3) == 0 && dfx::aligned16(y);
+    IgemmArgs g{x, wp, reinterpret_cast<const int2 *>(ktab), bias, y, Ci, H, W, Co, Ho, Wo, Kpad, stride, pad, act, KH, KW,
+                dilation, (long)Ci * H * W, (long)Co * Ho * Wo, wide};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Co <= 64) return launch<64, 1, 4>(g, N, st);
     const long t128 = (long)((Co + 127) / 128) * ((Ho * Wo + 127) / 128) * N;

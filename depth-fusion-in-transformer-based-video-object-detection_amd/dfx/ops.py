@@ -484,13 +484,22 @@ class ConvPlan:
                 w = w * scale.detach().reshape(-1, 1, 1, 1)
             K = kh * kw * Ci
             Kpad = (K + 15) // 16 * 16
-            _require(Ci < 65536 and (kh - 1) * dilation < 256 and (kw - 1) * dilation < 128, "ConvPlan: tap table range")
+            _require(kh * kw <= 64, "ConvPlan: at most 64 taps")
             wp = torch.zeros(Co, Kpad, dtype=torch.float32, device=w.device)
             wp[:, :K] = w.permute(0, 2, 3, 1).reshape(Co, K)
-            ky, kx, ci = torch.meshgrid(torch.arange(kh), torch.arange(kw), torch.arange(Ci), indexing="ij")
-            tab = torch.full((Kpad,), -1, dtype=torch.int32)
-            tab[:K] = (ci | ((ky * dilation) << 16) | ((kx * dilation) << 24)).reshape(-1).to(torch.int32)
-            self.wp, self.ktab, self.Kpad = wp, tab.to(w.device), Kpad
+            self.wp, self.Kpad, self.K, self._tabs = wp, Kpad, K, {}
+
+    def _ktab(self, H, W, device):
+        """Tap table of the implicit GEMM for an H x W input (include/dfx_conv.h): per k {tap index, byte offset}."""
+        key = (H, W, str(device))
+        if key not in self._tabs:
+            ky, kx, ci = torch.meshgrid(torch.arange(self.kh), torch.arange(self.kw), torch.arange(self.Ci), indexing="ij")
+            tab = torch.zeros((self.Kpad, 2), dtype=torch.int32)
+            tab[:, 0] = -1
+            tab[:self.K, 0] = (ky * self.kw + kx).reshape(-1).to(torch.int32)
+            tab[:self.K, 1] = ((ci * (H * W) + ky * self.dilation * W + kx * self.dilation) * 4).reshape(-1).to(torch.int32)
+            self._tabs[key] = tab.to(device)
+        return self._tabs[key]
 
     def out_size(self, H, W):
         eff_h, eff_w = (self.kh - 1) * self.dilation + 1, (self.kw - 1) * self.dilation + 1
@@ -508,9 +517,10 @@ class ConvPlan:
                 rc = lib.dfx_conv3x3_wino_f32(x.data_ptr(), self.u.data_ptr(), _ptr(self.bias), y.data_ptr(), N, self.Ci,
                                               H, W, self.Co, self.dilation, self.act, _stream(x.device))
             else:
-                rc = lib.dfx_conv2d_igemm_f32(x.data_ptr(), self.wp.data_ptr(), self.ktab.data_ptr(), _ptr(self.bias),
-                                              y.data_ptr(), N, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad, self.stride,
-                                              self.padding, self.act, _stream(x.device))
+                rc = lib.dfx_conv2d_igemm_f32(x.data_ptr(), self.wp.data_ptr(), self._ktab(H, W, x.device).data_ptr(),
+                                              _ptr(self.bias), y.data_ptr(), N, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad,
+                                              self.kh, self.kw, self.stride, self.padding, self.dilation, self.act,
+                                              _stream(x.device))
         _lib.check(rc, "conv " + self.algo)
         return y
 

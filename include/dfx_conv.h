@@ -27,16 +27,17 @@ extern "C" {
  *
  *   x     [N, Ci, H, W]
  *   wp    [Co, Kpad]  weights re-ordered by the caller so that column k multiplies the input element
- *                     that ktab[k] names; Kpad a multiple of 16 (pad columns: weight 0, ktab < 0)
- *   ktab  int32[Kpad] on the device: bits 0..15 input channel, bits 16..23 tap row offset (ky * dilation),
- *                     bits 24..30 tap column offset (kx * dilation); negative = padding column
+ *                     that ktab[k] names; Kpad a multiple of 16 (pad columns: weight 0, tap -1)
+ *   ktab  int32[Kpad][2] on the device, for this input geometry: {tap index ky * KW + kx (or -1: padding
+ *                     column), byte offset of the tap inside one image = 4 * (ci*H*W + ky*dilation*W + kx*dilation)}
  *   bias  [Co] or NULL
- *   y     [N, Co, Ho, Wo],  y = act(conv + bias[co]);  input pixel of tap (dy, dx) for output (oy, ox)
- *                           is (oy * stride - pad + dy, ox * stride - pad + dx), zero outside the map
+ *   y     [N, Co, Ho, Wo],  y = act(conv + bias[co]);  input pixel of tap (ky, kx) for output (oy, ox)
+ *                           is (oy*stride - pad + ky*dilation, ox*stride - pad + kx*dilation), zero outside the map
+ *   KH * KW <= 64
  */
 int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const float *bias, float *y,
-                         int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad,
-                         int stride, int pad, int act, void *stream);
+                         int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
+                         int stride, int pad, int dilation, int act, void *stream);
 
 /* 3x3, stride 1, padding = dilation ("same") convolution by Winograd F(2x2, 3x3) with every stage in one
  * kernel: input tiles are transformed while they are staged into LDS, the 16 element-wise products run as
