@@ -27,6 +27,7 @@
 // MFMA-bound: 2*16*Co*Ci flops per tile against 157 TFLOP/s = 2.25x the direct form's rate at equal speed.
 #include "dfx_common.h"
 #include "dfx_conv.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,6 +43,7 @@ struct WinoArgs {
     long strideX, strideY;
     int nchunk, ntb;     // Ci / 8, tile blocks
     unsigned xbytes, ubytes;
+    int lb0;             // first logical block of this launch
 };
 
 __device__ __forceinline__ float activate(float v, int act)
@@ -51,27 +53,45 @@ __device__ __forceinline__ float activate(float v, int act)
     return v;
 }
 
-constexpr int kCoB = 64, kTB = 64, kCK = 8;
-constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk (8192)
-constexpr int kVChunk = 16 * kCK * kTB;           // floats per V chunk (8192)
+constexpr int kCoB = 64, kTB = 64, kCK = 8;       // the weight tensor's blocking: 64 output channels x 8 input channels
+constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk of a 64-channel block (8192)
 
+// CB x TB = MFMA tiles (32 output channels x 32 Winograd tiles each) per workgroup and position.  <2,2> is the kernel
+// described above; <1,1> - a quarter of the output block, same 8 waves - covers the logical blocks that would
+// otherwise form a last, mostly empty round over the 256 CUs (and small problems altogether), sub-block by sub-block.
+template <int CB, int TB>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (kUChunk + kVChunk)];      // 128 KB
-    float *const Us = smem;                       // [2][kUChunk]
-    float *const Vs = smem + 2 * kUChunk;         // [2][kVChunk]
+    constexpr int CW = 32 * CB, TW = 32 * TB;                 // output channels / tiles of the workgroup
+    constexpr int UCH = 16 * 2 * CW * 4, VCH = 16 * kCK * TW; // floats per staged U / V chunk
+    constexpr int U_LD = UCH / 4 / 512;                       // float4 loads of U per thread and chunk (4 or 2)
+    constexpr int X_ITEMS = kCK * TW;                         // (input channel, tile) patches per chunk (512 or 256)
+    constexpr int MS = 16 * 8 * CB * TW;                      // floats of one epilogue pass
+    constexpr int SM = 2 * (UCH + VCH) > 2 * MS ? 2 * (UCH + VCH) : 2 * MS;
+    __shared__ __attribute__((aligned(16))) float smem[SM];   // 128 KB for <2,2>
+    float *const Us = smem;                       // [2][UCH]   [pos][kq][co][4]
+    float *const Vs = smem + 2 * UCH;             // [2][VCH]   [pos][ci][tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, c = lane & 31;
 
     // XCD-aware decode: logical block = co block (slow) x tile block (fast); each XCD walks one contiguous range,
     // so the U slice of a co block stays in that XCD's L2
-    const int lb = dfx::xcd_remap(blockIdx.x, gridDim.x);
+    int lb, cq = 0, tq = 0;
+    if (CB == 2) {
+        lb = g.lb0 + dfx::xcd_remap(blockIdx.x, gridDim.x);
+    } else {
+        const int q = dfx::xcd_remap(blockIdx.x, gridDim.x);
+        lb = g.lb0 + (q >> 2);
+        cq = (q >> 1) & 1;
+        tq = q & 1;
+    }
     const int cob = lb / g.ntb, tb = lb - cob * g.ntb;
-    const int co0 = cob * kCoB;
+    const int co0 = cob * kCoB + cq * 32;
 
-    // this thread's tile (the same tile for the input patch it loads and the outputs it writes)
-    const long t = (long)tb * kTB + lane;
+    // this thread's tile (the same tile for the input patch it loads and the outputs it writes) and input channel
+    const int tl = tid % TW, cil = tid / TW;                  // (tid < X_ITEMS: patch loader)
+    const long t = (long)tb * kTB + tq * 32 + tl;
     const bool tv = t < g.tiles;
     const long tc = tv ? t : 0;
     const int per_img = g.TY * g.TX;
@@ -97,41 +117,52 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // (checked on the host: the whole input < 2^32 bytes); 16 offset registers, no 64-bit address arithmetic
     unsigned xoff[16];
     {
-        const unsigned b = (unsigned)((long)n * g.strideX) + (unsigned)(wave * HW);
+        const unsigned b = (unsigned)((long)n * g.strideX) + (unsigned)((cil & (kCK - 1)) * HW);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xoff[i * 4 + j] = (b + (unsigned)(roff[i] + coff[j])) * 4u;
     }
+    const bool xloader = X_ITEMS == 512 || tid < X_ITEMS;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.X), 0, (int)g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.U), 0, (int)g.ubytes, 0x00020000);
     const unsigned ubase = (unsigned)cob * g.nchunk * (kUChunk * 4u);
+    // U: the chunk of the 64-channel block is [pos][kq][64 co][4]; this workgroup stages its CW channels of every row
+    unsigned uoff[U_LD];
+#pragma unroll
+    for (int i = 0; i < U_LD; ++i) {
+        const int f = tid + i * 512, row = f / CW, col = f % CW;
+        uoff[i] = (unsigned)((row * kCoB + cq * 32 + col) * 16);
+    }
 
-    f32x16 acc[2][2][2];      // [position][co tile][tile tile]
+    f32x16 acc[2][CB][TB];      // [position][co tile][tile tile]
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
 
     float xr[16];
-    f32x4 ur[4];
+    f32x4 ur[U_LD];
     auto load_chunk = [&](int ch) {
         const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offsets
         const unsigned us = ubase + (unsigned)ch * (kUChunk * 4u);
+        if (xloader) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[i], xs, 0));
+            for (int i = 0; i < 16; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[i], xs, 0));
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, (unsigned)(tid * 16 + i * 8192), us, 0));
+        for (int i = 0; i < U_LD; ++i)
+            ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff[i], us, 0));
     };
     auto store_chunk = [&](int buf) {
-        float *us = Us + buf * kUChunk + tid * 4;
+        float *us = Us + buf * UCH + tid * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(us + i * 2048) = ur[i];
+        for (int i = 0; i < U_LD; ++i) *reinterpret_cast<f32x4 *>(us + i * 2048) = ur[i];
+        if (!xloader) return;
         // B^T d B
         float dd[16], tm[16];
 #pragma unroll
@@ -146,13 +177,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             tm[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
             tm[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
         }
-        float *vs = Vs + buf * kVChunk + wave * kTB + lane;       // [pos][ci = wave][tile = lane]
+        float *vs = Vs + buf * VCH + cil * TW + tl;               // [pos][ci][tile]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            vs[(i * 4 + 0) * (kCK * kTB)] = tm[i * 4 + 0] - tm[i * 4 + 2];
-            vs[(i * 4 + 1) * (kCK * kTB)] = tm[i * 4 + 1] + tm[i * 4 + 2];
-            vs[(i * 4 + 2) * (kCK * kTB)] = tm[i * 4 + 2] - tm[i * 4 + 1];
-            vs[(i * 4 + 3) * (kCK * kTB)] = tm[i * 4 + 1] - tm[i * 4 + 3];
+            vs[(i * 4 + 0) * (kCK * TW)] = tm[i * 4 + 0] - tm[i * 4 + 2];
+            vs[(i * 4 + 1) * (kCK * TW)] = tm[i * 4 + 1] + tm[i * 4 + 2];
+            vs[(i * 4 + 2) * (kCK * TW)] = tm[i * 4 + 2] - tm[i * 4 + 1];
+            vs[(i * 4 + 3) * (kCK * TW)] = tm[i * 4 + 1] - tm[i * 4 + 3];
         }
     };
 
@@ -177,19 +208,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         __builtin_amdgcn_sched_barrier(0);
         // operand fragments of both positions up front: the second position's LDS reads complete under the
         // first position's MFMAs
-        f32x4 af[2][2];
-        float bf[2][4][2];
+        f32x4 af[2][CB];
+        float bf[2][4][TB];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int pos = wave * 2 + p;
-            const float *ub = Us + buf * kUChunk + (pos * 2 + half) * (kCoB * 4) + c * 4;
-            const float *vb = Vs + buf * kVChunk + (pos * kCK + half * 4) * kTB + c;
+            const float *ub = Us + buf * UCH + (pos * 2 + half) * (CW * 4) + c * 4;
+            const float *vb = Vs + buf * VCH + (pos * kCK + half * 4) * TW + c;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const f32x4 *>(ub + i * 32 * 4);
+            for (int i = 0; i < CB; ++i) af[p][i] = *reinterpret_cast<const f32x4 *>(ub + i * 32 * 4);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[p][tt][j] = vb[tt * kTB + j * 32];
+                for (int j = 0; j < TB; ++j) bf[p][tt][j] = vb[tt * TW + j * 32];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -197,10 +228,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < CB; ++i) {
                     const float av = af[p][i][tt];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TB; ++j)
                         acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[p][tt][j], acc[p][i][j], 0, 0, 0);
                 }
             }
@@ -215,26 +246,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // compacted to cl = i*8 + 4*half + rr
     float *Y = g.Y + (long)n * g.strideY;
     const int P = HW;
+    constexpr int ITEMS = 8 * CB * TW;                          // (co row, tile) outputs per pass
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float *ms = smem + (q & 1) * (16 * 16 * kTB);            // [16 pos][16 cl][64 tiles]
+        float *ms = smem + (q & 1) * MS;                        // [16 pos][8*CB cl][TW tiles]
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CB; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TB; ++j)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
-                        ms[((wave * 2 + p) * 16 + i * 8 + 4 * half + rr) * kTB + j * 32 + c] = acc[p][i][j][4 * q + rr];
+                        ms[((wave * 2 + p) * (8 * CB) + i * 8 + 4 * half + rr) * TW + j * 32 + c] = acc[p][i][j][4 * q + rr];
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int cl = wave + 8 * s;
+        for (int s = 0; s < (ITEMS + 511) / 512; ++s) {
+            const int idx = tid + s * 512;
+            if (ITEMS < 512 && idx >= ITEMS) break;
+            const int cl = idx / TW;                            // (idx % TW == tl: this thread's tile)
             const int co = co0 + (cl >> 3) * 32 + 8 * q + (cl & 7);
             float m[16];
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) m[pos] = ms[(pos * 16 + cl) * kTB + lane];
+            for (int pos = 0; pos < 16; ++pos) m[pos] = ms[(pos * (8 * CB) + cl) * TW + tl];
             float t0[4], t1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -318,12 +352,30 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     g.ubytes = (unsigned)((long)16 * Co * Ci * 4);
     const long ntb = (g.tiles + kTB - 1) / kTB;
     const long blocks = ntb * (Co / kCoB);
-    if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "conv3x3_wino: grid too large");
+    if (blocks >= (1L << 29)) return dfx::fail(DFX_ERANGE, "conv3x3_wino: grid too large");
     g.ntb = (int)ntb;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // One 512-thread workgroup per CU: the launch runs in rounds of 256 logical blocks.  A last round that would fill
+    // at most ~60 % of the CUs is run as quarter-size workgroups instead (4 per block: ~0.3 of a round when they fit
+    // the chip at once); a problem smaller than one round is all quarter-size.
+    const long rem = blocks % 256, full = blocks - rem;
+    const bool quarter_tail = rem > 0 && rem <= 160 && !getenv("DFX_WINO_NO_TAIL");
+    const long main_blocks = quarter_tail ? full : blocks;
+    const long flops_per_block = 2L * 16 * kCoB * Ci * kTB;
     // measurement aid (dfx_profile_*): MFMA flops the launch executes (16 products per 2x2 output tile, padded tiles
     // included) in the byte field, tag_a = -3, tag_b = dilation; the direct form's flops are 2.25x as many
-    dfx::launch_timed(2L * 16 * Co * Ci * g.tiles, -3, dilation, conv_wino_kernel, dim3((unsigned)blocks), dim3(512), 0,
-                      static_cast<hipStream_t>(stream), g);
+    if (main_blocks > 0) {
+        g.lb0 = 0;
+        dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2>, dim3((unsigned)main_blocks),
+                          dim3(512), 0, st, g);
+        const int rc = dfx::check_launch("conv_wino_kernel");
+        if (rc != DFX_OK) return rc;
+    }
+    if (quarter_tail) {
+        g.lb0 = (int)full;
+        dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1>, dim3((unsigned)(rem * 4)), dim3(512), 0,
+                          st, g);
+    }
     return dfx::check_launch("conv_wino_kernel");
 }
 

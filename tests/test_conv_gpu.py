@@ -54,6 +54,8 @@ WINO = [  # N, Ci, Co, H, W, dil
     (1, 64, 128, 50, 84, 2),
     (5, 8, 64, 7, 5, 1),           # tiles of several images inside one workgroup
     (2, 16, 64, 9, 10, 3),
+    (8, 64, 64, 100, 167, 1),      # 525 logical blocks: two full rounds of 64x64 workgroups + 13 blocks as quarter-size ones
+    (4, 256, 256, 50, 84, 2),      # 276 blocks
 ]
 
 
