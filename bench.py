@@ -166,11 +166,11 @@ def main():
     ap.add_argument("--overlap", type=int, default=1,
                     help="two-stream schedule inside a rank: backbones of micro-batch i+1 beside the transformer "
                          "tail of micro-batch i (ClipRunner; same results)")
-    ap.add_argument("--pipeline", type=int, default=0,
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="clips are a stream: queue each step with ClipRunner.submit, so the transformer tail of clip k "
-                         "runs on a second HIP stream beside the backbones of clip k+1 (same results; 0 = one clip at a "
-                         "time on one stream - the default, so that the MSDA kernel's stamped times in the timed region are "
-                         "its own; 1 = on for a single GPU: +3-4 %% frames/s; 2 = on for N > 1 as well)")
+                         "runs on a second HIP stream beside the backbones of clip k+1 (same results, +5 %% frames/s; 0 = one "
+                         "clip at a time on one stream; 1 = on for a single GPU - the default; the per-kernel roofline "
+                         "durations then come from one extra single-stream step; 2 = on for N > 1 as well)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="ask MIOpen for run-to-run deterministic convolution solvers (costs ~6 %% here)")
     ap.add_argument("--backend", default="nccl",
@@ -311,7 +311,7 @@ def main():
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TransVOD++ LateFusion, {a.frames}-frame {a.height}x{a.width} RGB-D clip, "
-                                   f"all-current mode (R={a.frames - 1}), L=1 DC5 (S=4200), 300 queries, 3 classes",
+                                   f"all-current mode (R={a.frames - 1}), L=1 DC5 (S={-(-a.height // 16) * -(-a.width // 16)}), 300 queries, 3 classes",
                        "frames_per_gpu": per_rank, "micro_batch": min(a.micro_batch, per_rank),
                        "parallelism": f"frame-shard x{world} + 1 all-gather/clip",
                        "two_stream_overlap": overlapped, "clip_pipeline": pipelined},

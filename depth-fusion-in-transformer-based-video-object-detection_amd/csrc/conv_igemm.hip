@@ -228,7 +228,7 @@ int launch(const IgemmArgs &g, int N, hipStream_t st)
 
 extern "C" int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const float *bias, float *y,
                                     int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
-                                    int stride, int pad, int dilation, int act, void *stream)
+                                    int stride, int pad, int dilation, int act, long x_image_stride, void *stream)
 {
     if (N < 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || Ho < 0 || Wo < 0 || Kpad <= 0 || stride <= 0 || pad < 0 ||
         KH <= 0 || KW <= 0 || dilation <= 0)
@@ -243,7 +243,7 @@ extern "C" int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *
     if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "conv2d_igemm: unknown activation");
     const int wide = ((Ho * Wo) & 3) == 0 && dfx::aligned16(y);
     IgemmArgs g{x, wp, reinterpret_cast<const int2 *>(ktab), bias, y, Ci, H, W, Co, Ho, Wo, Kpad, stride, pad, act, KH, KW,
-                dilation, (long)Ci * H * W, (long)Co * Ho * Wo, wide};
+                dilation, x_image_stride > 0 ? x_image_stride : (long)Ci * H * W, (long)Co * Ho * Wo, wide};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Co <= 64) return launch<64, 1, 4>(g, N, st);
     const long t128 = (long)((Co + 127) / 128) * ((Ho * Wo + 127) / 128) * N;

@@ -313,7 +313,13 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
     const int PL = (int)plane_tokens(H, W);
     const size_t lds = (size_t)2 * PL * 16;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool raised = false;                     // LDS images above 64 KB need the per-function opt-in
+    // LDS images above 64 KB need the per-function opt-in, once per DEVICE (the attribute is per device context)
+    static std::mutex raise_mu;
+    static bool raised_on[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> raise_lock(raise_mu);
+    bool &raised = raised_on[dev & 63];
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_level<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess ||

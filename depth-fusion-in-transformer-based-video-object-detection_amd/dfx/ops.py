@@ -507,9 +507,15 @@ class ConvPlan:
 
     def __call__(self, x):
         lib = _lib.load()
-        _check_inputs([("x", x)])
-        _require(x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.Ci, "conv: x must be [N,Ci,H,W] fp32")
+        _require(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.Ci,
+                 "conv: x must be a CUDA fp32 tensor [N,Ci,H,W] (no CPU path)")
         N, _, H, W = x.shape
+        # a channel slice of a wider NCHW tensor (x[:, :3] of an RGB-D clip) is read in place by the implicit GEMM
+        sliced = (self.algo == "igemm" and not x.is_contiguous() and x.stride(3) == 1 and x.stride(2) == W
+                  and x.stride(1) == H * W and x.stride(0) >= self.Ci * H * W)
+        image_stride = x.stride(0) if sliced else 0
+        if not sliced:
+            x = x.contiguous()
         Ho, Wo = self.out_size(H, W)
         y = torch.empty((N, self.Co, Ho, Wo), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -520,7 +526,7 @@ class ConvPlan:
                 rc = lib.dfx_conv2d_igemm_f32(x.data_ptr(), self.wp.data_ptr(), self._ktab(H, W, x.device).data_ptr(),
                                               _ptr(self.bias), y.data_ptr(), N, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad,
                                               self.kh, self.kw, self.stride, self.padding, self.dilation, self.act,
-                                              _stream(x.device))
+                                              image_stride, _stream(x.device))
         _lib.check(rc, "conv " + self.algo)
         return y
 

@@ -119,7 +119,6 @@ class DFormerBackbone(nn.Module):
                 # hand-written implicit-GEMM convolution, bias + GELU in its epilogue (csrc/conv_igemm.hip)
                 plan.append(_ops.ConvPlan(w, b, conv.stride, conv.padding, conv.dilation, "gelu" if gelu else None))
             self._folded = (key, plan)
-        x = x.contiguous()
         for conv in self._folded[1]:
             x = conv(x)
         return x

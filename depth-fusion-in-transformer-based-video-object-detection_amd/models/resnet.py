@@ -133,7 +133,7 @@ class ResNet50(nn.Module):
             self._stem_folded = (key, (_ops.ConvPlan(self.conv1.weight, None, 2, 3, 1, None, scale=scale.detach()),
                                        shift.detach().contiguous()))
         plan, b = self._stem_folded[1]
-        return _ops.bias_relu_maxpool(plan(x.contiguous()), b)
+        return _ops.bias_relu_maxpool(plan(x), b)
 
     def run_stage(self, stage, x, fused=False):
         if not fused:

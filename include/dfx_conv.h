@@ -25,7 +25,8 @@ extern "C" {
 /* Direct convolution as an implicit GEMM  Y_n[Co, Ho*Wo] = Wp[Co, Kpad] x im2col(X_n)[Kpad, Ho*Wo]
  * with the gather done while the operand tile is staged into LDS (no im2col buffer exists).
  *
- *   x     [N, Ci, H, W]
+ *   x     [N, Ci, H, W]; x_image_stride = elements between consecutive images (0: packed, Ci*H*W) - a channel
+ *                     slice of a wider tensor (the RGB / depth planes of an RGB-D clip) is read in place
  *   wp    [Co, Kpad]  weights re-ordered by the caller so that column k multiplies the input element
  *                     that ktab[k] names; Kpad a multiple of 16 (pad columns: weight 0, tap -1)
  *   ktab  int32[Kpad][2] on the device, for this input geometry: {tap index ky * KW + kx (or -1: padding
@@ -37,7 +38,7 @@ extern "C" {
  */
 int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const float *bias, float *y,
                          int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
-                         int stride, int pad, int dilation, int act, void *stream);
+                         int stride, int pad, int dilation, int act, long x_image_stride, void *stream);
 
 /* 3x3, stride 1, padding = dilation ("same") convolution by Winograd F(2x2, 3x3) with every stage in one
  * kernel: input tiles are transformed while they are staged into LDS, the 16 element-wise products run as

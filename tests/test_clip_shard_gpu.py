@@ -123,3 +123,22 @@ def test_clip_pipeline_submit_matches_call():
                 assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = saved
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_two_ranks_gloo_rehearsal(tmp_path):
+    """bench.py's own N > 1 code path (rank / world from the environment, frame sharding, barrier, MAX over ranks,
+    rank 0 prints the line) with two ranks sharing this GPU over gloo - a rehearsal of the driver's RCCL launch on a
+    small clip.  The line must parse and describe a 2-rank run."""
+    import json
+    import subprocess
+    port = 29700 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4",
+           "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["config"]["frames_per_gpu"] == 2 and line["roofline"]["bound"] == "mfma"

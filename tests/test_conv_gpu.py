@@ -96,3 +96,14 @@ def test_conv_plan_rejects_cpu_and_bad_geometry():
     assert ops.ConvPlan(w, None, 1, 1, 1).algo == "igemm"       # Ci % 8 != 0 -> implicit GEMM
     with pytest.raises(RuntimeError):
         ops.ConvPlan(w, None, 1, 1, 1, algo="wino")
+
+
+def test_igemm_reads_a_channel_slice_in_place():
+    """x[:, :3] / x[:, 3:4] of an RGB-D clip go to the stem convolutions without a copy (image stride argument)."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 4, 37, 50, generator=g).cuda()
+    for sl, ci in ((slice(0, 3), 3), (slice(3, 4), 1)):
+        w = torch.randn(16, ci, 3, 3, generator=g).cuda()
+        plan = ops.ConvPlan(w, None, 2, 1, 1, None)
+        assert torch.equal(plan(x[:, sl]), plan(x[:, sl].contiguous()))

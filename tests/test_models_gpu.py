@@ -262,3 +262,49 @@ def test_padded_clip_gpu_vs_cpu_oracle():
     valid = ~torch.nn.functional.interpolate(mask[None].float(), size=(4, 6)).bool()[0].flatten(1)      # stride-16 map
     diff = (got["memory"].cpu() - want["memory"]).abs().max(-1)[0]
     assert (diff * valid).max() < 1e-3
+
+
+def test_config_a_single_image_794x600_gpu_vs_cpu_oracle():
+    """BASELINE.json configs[0]: single-frame RGB Deformable-DETR on ONE image at the size the reference's
+    sample_dataset/OID image takes after its resize (773x1024 -> short side 600: [1,3,794,600], 1900 tokens after
+    DC5): odd map sizes all the way down (H*W % 4 != 0 on some stages: the implicit-GEMM route of the 1x1
+    convolutions, Winograd edge tiles).  HIP path vs the same host code on CPU with the oracle operators;
+    PostProcess labels / box indices index by index outside a 2e-5 tie margin."""
+    from models import build_model
+    from models.config import single_args
+    from models.fused import enable_fused_inference
+    from tests._cases_detector import compare_indices
+    from tests._param_fill import fill_params_by_name
+    from util.misc import nested_tensor_from_tensor_list
+    img = torch.randn(3, 794, 600, generator=torch.Generator().manual_seed(21))
+
+    def make(device):
+        model, _, post = build_model(single_args("Baseline", device=device))
+        fill_params_by_name(model, seed=8)
+        with torch.no_grad():
+            for h in model.bbox_embed:
+                h.layers[-1].weight.mul_(0.2)
+        return model.to(device).eval(), post
+
+    gm, post = make("cuda")
+    enable_fused_inference(gm)
+    with torch.no_grad():
+        got = gm(nested_tensor_from_tensor_list([img.cuda()]))
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = make("cpu")
+        with torch.no_grad():
+            want = cm(nested_tensor_from_tensor_list([img]))
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    lg, bx = got["pred_logits"].cpu(), got["pred_boxes"].cpu()
+    assert lg.shape == (1, 300, 3)
+    assert (lg - want["pred_logits"]).abs().max() < 1e-3 and (bx - want["pred_boxes"]).abs().max() < 1e-3
+    sizes = torch.tensor([[794, 600]])
+    rg, rc = post["bbox"]({"pred_logits": lg, "pred_boxes": bx}, sizes)[0], post["bbox"](want, sizes)[0]
+    n, bad = compare_indices(rc["labels"][None], rg["labels"][None], rc["scores"][None], 2e-5)
+    assert n > 10 and bad == 0
+    idx_c = torch.topk(want["pred_logits"].sigmoid().flatten(1), 100, dim=1)[1] // 3
+    idx_g = torch.topk(lg.sigmoid().flatten(1), 100, dim=1)[1] // 3
+    n, bad = compare_indices(idx_c, idx_g, rc["scores"][None], 2e-5)
+    assert n > 10 and bad == 0
