@@ -384,6 +384,8 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     {
         const long t128x128 = (long)((M + 127) / 128) * ((N + 127) / 128) * zb;
         const bool rows_fit = (M % 128 == 0) || M >= 1024;
+        // split-K launches are sized by the caller to fill one resident round of 128 x 128 tiles (3 per CU)
+        if (g.splits > 1 && M >= 128 && N >= 128 && t128x128 <= 768) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
         if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 512)))
             return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     }

@@ -266,12 +266,18 @@ def _ptr(t):
 
 
 def _split_k(M, N, K):
-    """Number of K ranges for a GEMM with few output tiles and a long K (0 = no split): aim at ~3 workgroups per
-    CU, at least 32 K-steps per range."""
-    tiles = -(-M // 64) * -(-N // 128)
-    if tiles >= 512 or K < 2048:
+    """Number of K ranges for a GEMM with few output tiles and a long K (0 = no split): as many as keep the
+    128 x 128 (or 64 x 128 for small M) tiles x ranges within one resident round of workgroups (3 per CU for the
+    large tile, 4 for the small one), at least 32 K-steps per range."""
+    if K < 2048:
         return 0
-    return max(1, min(K // 512, 768 // tiles))
+    if M >= 128 and N >= 128:
+        tiles, slots = -(-M // 128) * -(-N // 128), 768
+    else:
+        tiles, slots = -(-M // 64) * -(-N // 128), 1024
+    if tiles * 2 > slots:
+        return 0
+    return max(1, min(K // 512, slots // tiles))
 
 
 def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False,
