@@ -61,6 +61,9 @@ torch.backends.cudnn.allow_tf32 = False
 # profiles/r01_pmc_msda_level_N8.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 8 frames, the
 # factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
 MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
+# fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
+# family's launches per step, from the PMC passes over this workload committed in profiles/r02_pmc_traffic.md
+FAMILY_TRAFFIC_PER_STEP = {"gemm": (206167.2e6, 214), "wino": (18843.8e6, 28), "igemm": (20166.1e6, 7)}
 
 # per-frame algorithmic work of config E (all-current mode)
 BYTES_PER_FRAME = 4.333e9
@@ -269,8 +272,12 @@ def main():
             if not rec:
                 continue
             tsum, wsum = sum(x for x, _ in rec), sum(w for _, w in rec)
+            tr_key = {-3: "wino", -4: "igemm"}.get(tag)
+            traffic = None
+            if tr_key and a.frames == 32 and a.height == 800 and a.width == 1333:      # per launch, scaled to the rank's frames
+                traffic = int(FAMILY_TRAFFIC_PER_STEP[tr_key][0] / FAMILY_TRAFFIC_PER_STEP[tr_key][1] * per_rank / 32)
             kernels.append({"kernel": name, "bound": bound, "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12,
-                            "unit": "TFLOP/s", "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": traffic,
                             "launches_per_step": round(len(rec) / steps_profiled, 1),
                             "flops_per_step": wsum / steps_profiled, "ms_per_step": round(tsum / steps_profiled * 1e3, 3),
                             "share_of_step": round(tsum / steps_profiled / step_s, 4)})
@@ -281,7 +288,11 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (fp32 MFMA GEMM: every 1x1 convolution and Linear; the family "
                                                "with the largest share of GPU time)",
                     "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": None,
+                    "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4),
+                    "traffic": (int(FAMILY_TRAFFIC_PER_STEP["gemm"][0] / FAMILY_TRAFFIC_PER_STEP["gemm"][1] * per_rank / 32)
+                                if a.frames == 32 and a.height == 800 and a.width == 1333 else None),
+                    "traffic_source": "PMC 2 x FETCH_SIZE + WRITE_SIZE (HBM + Infinity Cache side of L2), average per launch of "
+                                      "the family, profiles/r02_pmc_traffic.md",
                     "launches": len(gemm), "flops_per_launch": wsum / len(gemm), "avg_launch_us": round(tsum / len(gemm) * 1e6, 2),
                     "share_of_step": round(tsum / steps_profiled / step_s, 4),
                     "measured": "HIP events stamped by each launch, timed region; achieved = sum of 2*M*N*K / sum of durations"}
