@@ -114,3 +114,49 @@ def test_memo_on_tensor_identity_and_version():
         memo.memo_on(m, "x", lambda: build(m))
         assert len(calls) == 6                                                             # no caching under autograd
     memo.clear()
+
+
+# ---- pinned against the REFERENCE's inference.py (tools/gen_golden_inference.py -> tests/golden/inference_io.npz) ----
+def _golden():
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inference_io.npz"))
+
+
+def test_size_rule_matches_reference_resize():
+    """inference.py:310-353 (short side `size`, long side capped at `max_size`, int truncation)."""
+    from models.preprocess import get_size_with_aspect_ratio
+    for w, h, size, max_size, oh, ow in _golden()["resize.cases"].tolist():
+        assert tuple(get_size_with_aspect_ratio((w, h), size, max_size)) == (oh, ow)
+
+
+def test_rescale_bboxes_matches_reference():
+    """inference.py:456-489."""
+    import torch
+    from models.inference_io import rescale_bboxes
+    g = _golden()
+    boxes = torch.from_numpy(g["rescale.boxes"])
+    for key, size in (("rescale.xyxy_640x480", (640, 480)), ("rescale.xyxy_1333x800", (1333, 800))):
+        assert torch.equal(rescale_bboxes(boxes, size), torch.from_numpy(g[key]))
+
+
+def test_reference_frame_sampling_and_clip_assembly_match_reference():
+    """inference.py:721-794 run on a synthetic COCO-VID index whose images are constants carrying their id: the
+    reference's output row for image i is [id, id, id, (-id)] for the key frame followed by its reference frames."""
+    import torch
+    from models.inference_io import assemble_clip, sample_reference_ids
+    g = _golden()
+    video_of = {int(i): int(v) for i, v in g["clips.video_of_image"]}
+    videos = {}
+    for i, v in video_of.items():
+        videos.setdefault(v, []).append(i)
+    for key in [k for k in g.files if k.startswith("clips.R")]:
+        num_ref = int(key.split("R")[1].split("_")[0])
+        filt, depth = "filter1" in key, "depth1" in key
+        want = torch.from_numpy(g[key])
+        for row, img_id in enumerate(sorted(video_of)):
+            refs = sample_reference_ids(img_id, sorted(videos[video_of[img_id]]), num_ref, filter_key_img=filt)
+            ids = [img_id] + refs
+            rgb = [torch.full((3, 2, 2), float(i)) for i in ids]
+            dep = [torch.full((1, 2, 2), -float(i)) for i in ids] if depth else None
+            assert torch.equal(assemble_clip(rgb, dep)[:, 0, 0], want[row]), (key, img_id)

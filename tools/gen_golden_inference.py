@@ -1,0 +1,128 @@
+"""Generate golden vectors for the inference CALLER's helper steps from the REFERENCE's inference.py
+(build container only):   python tools/gen_golden_inference.py   ->  tests/golden/inference_io.npz
+
+inference.py imports cv2, pycocotools, matplotlib, tqdm and torchvision.transforms at module level; none exists in this
+image and none is used by the helpers pinned here, so they are satisfied by EMPTY placeholder modules (the recipe of
+SURVEY.md 8c / tools/ref_import.py extended by import-only names).  What is called is the reference's own code:
+
+  * ``resize`` -> ``get_size_with_aspect_ratio``                         inference.py:310-353  (size rule: short side / max side)
+  * ``DeformableDETR.rescale_bboxes`` / ``box_cxcywh_to_xyxy``           inference.py:456-489
+  * ``DeformableDETR.get_image_and_reference_clips``                     inference.py:721-794  (reference-frame window,
+    repetition, key-frame filter, [ (1+R)*C, H, W ] channel assembly) on a synthetic COCO-VID index whose "images"
+    are constant tensors carrying their image id, so the output encodes which frames were sampled in which order.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+
+ref_import.install(roi_align_fn=None)
+
+
+def _placeholder(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+
+tv = sys.modules["torchvision"]
+tvt = _placeholder("torchvision.transforms", ToPILImage=_Any, Resize=_Any, Compose=_Any, ToTensor=_Any, Normalize=_Any)
+tvf = _placeholder("torchvision.transforms.functional", resize=lambda image, size: ("resized", tuple(size)))
+tvt.functional = tvf
+tv.transforms = tvt
+_placeholder("cv2")
+_placeholder("tqdm", tqdm=lambda x, *a, **k: x)
+mpl = _placeholder("matplotlib")
+mpl.pyplot = _placeholder("matplotlib.pyplot")
+pc = _placeholder("pycocotools")
+pc.coco = _placeholder("pycocotools.coco", COCO=_Any)
+pc.mask = _placeholder("pycocotools.mask")
+ds = _placeholder("datasets")
+ds.__path__ = []
+ds.coco_video_parser = _placeholder("datasets.coco_video_parser", CocoVID=_Any)
+sys.modules["models"].build_model = None                 # inference.py does ``from models import build_model``
+
+import inference as ref  # noqa: E402
+
+blobs = {}
+
+# ---- size rule -------------------------------------------------------------------------------------------------------
+SIZE_CASES = [(1024, 773, 600, 1333), (773, 1024, 600, 1333), (1333, 800, 800, 1333), (1920, 1080, 800, 1333), (640, 480, 600, 1333),
+              (500, 500, 600, 1333), (3000, 400, 600, 1333), (400, 3000, 600, 1333), (600, 900, 600, 1333), (999, 562, 600, 1000)]
+out = []
+for w, h, size, max_size in SIZE_CASES:
+    tag, (oh, ow) = ref.resize(types.SimpleNamespace(size=(w, h)), size, max_size)
+    out.append((w, h, size, max_size, oh, ow))
+blobs["resize.cases"] = np.asarray(out, dtype=np.int64)
+
+# ---- box rescale -----------------------------------------------------------------------------------------------------
+me = object.__new__(ref.DeformableDETR)
+boxes = torch.rand(37, 4, generator=torch.Generator().manual_seed(5))
+blobs["rescale.boxes"] = boxes.numpy()
+blobs["rescale.xyxy_640x480"] = ref.DeformableDETR.rescale_bboxes(me, boxes, (640, 480)).numpy()
+blobs["rescale.xyxy_1333x800"] = ref.DeformableDETR.rescale_bboxes(me, boxes, (1333, 800)).numpy()
+
+# ---- reference-frame sampling + clip assembly --------------------------------------------------------------------------
+VIDEOS = {1: list(range(1, 8)), 2: list(range(8, 10)), 3: list(range(10, 31))}      # image ids per video
+
+
+class FakeCoco:
+    imgs = {i: None for ids in VIDEOS.values() for i in ids}
+
+    def getAnnIds(self, imgIds):
+        return []
+
+    def loadAnns(self, ids):
+        return []
+
+    def loadImgs(self, i):
+        vid = next(v for v, ids in VIDEOS.items() if i in ids)
+        return [{"file_name": f"{i}", "video_id": vid}]
+
+
+class FakeVid:
+    def get_img_ids_from_vid(self, vid):
+        return VIDEOS[vid]
+
+
+def sampled(num_ref, filter_key, depth):
+    me = object.__new__(ref.DeformableDETR)
+    me.coco, me.cocovid = FakeCoco(), FakeVid()
+    me.num_ref_frames, me.filter_key_img, me.depth_available, me.img_path = num_ref, filter_key, depth, ""
+    me.get_image = lambda path: float(path)
+    me.get_depth = lambda path: -float(path)
+    me.prepare = lambda img, d, target: (img, d, target)
+    me.rgb_transform = lambda v: torch.full((3, 2, 2), v)
+    me.depth_transform = lambda v: torch.full((1, 2, 2), v)
+    rows = []
+    ids = sorted(FakeCoco.imgs)
+    for idx in range(len(ids)):
+        clip, target, path = ref.DeformableDETR.get_image_and_reference_clips(me, idx)
+        rows.append(clip[:, 0, 0])
+    return torch.stack(rows)
+
+
+for num_ref, filter_key, depth in ((4, True, True), (2, False, False), (31, True, True), (1, True, False)):
+    blobs[f"clips.R{num_ref}_filter{int(filter_key)}_depth{int(depth)}"] = sampled(num_ref, filter_key, depth).numpy()
+blobs["clips.video_of_image"] = np.asarray([[i, v] for v, ids in VIDEOS.items() for i in ids], dtype=np.int64)
+
+OUT = os.path.join(ROOT, "tests", "golden", "inference_io.npz")
+np.savez_compressed(OUT, **blobs)
+print("wrote", OUT, {k: v.shape for k, v in blobs.items()})
