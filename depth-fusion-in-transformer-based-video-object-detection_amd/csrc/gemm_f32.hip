@@ -181,6 +181,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
         }
     };
 
+    // Residual prefetch (64-row tiles only: 8 float4 per thread): a short K (Bottleneck.conv3: 4-16 K-steps) leaves the
+    // epilogue's residual loads nothing to hide behind, so they are issued here, before the K loop, through a buffer
+    // descriptor of the residual's exact extent (rows / columns outside the problem return zeros, never used).
+    constexpr bool PREFETCH_R = BM == 64 && BN == 128;
+    constexpr int R_F4 = 64 * BN / 4 / 256;
+    f32x4 rpre[PREFETCH_R ? R_F4 : 1];
+    const bool use_rpre = PREFETCH_R && g.R && g.wide_epilogue;
+    if (PREFETCH_R && use_rpre) {
+        const float *Rb = g.R + bz * g.strideR;
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Rb), 0, (int)(((long)(g.M - 1) * g.ldr + g.N) * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < R_F4; ++i) {
+            const int f = tid + i * 256, row = f / (BN / 4), c4 = f % (BN / 4);
+            const int m = m0 + row, n = n0 + c4 * 4;
+            const unsigned o = (m < g.M && n < g.N) ? ((unsigned)m * (unsigned)g.ldr + (unsigned)n) * 4u : 0x80000000u;
+            rpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, o, 0, 0));
+        }
+    }
     const int steps = (K + BK - 1) / BK;
     load_tiles(0);
     store_tiles(0);
@@ -271,7 +289,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
                 if (brow) { const float b = g.bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
                 if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (PREFETCH_R && use_rpre) { const f32x4 q = rpre[PREFETCH_R ? f0 / 256 : 0]; v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
+                else if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                 if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
                 if (mask && mask[m]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(C + (long)m * g.ldc + n) = v;
@@ -344,7 +363,8 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     {   // 32-bit byte offsets inside one batch element's operands (buffer loads)
         const long ea = a_block_stride > 0 ? (long)(K / 4) * a_block_stride : (long)M * lda;
         const long eb = b_is_kn ? (long)K * ldb : (long)N * ldb;
-        if (ea * 4 >= (1L << 31) || eb * 4 >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: an operand exceeds 2 GiB per batch element");
+        if (ea * 4 >= (1L << 31) || eb * 4 >= (1L << 31) || (R && (long)M * ldr * 4 >= (1L << 31)))
+            return dfx::fail(DFX_ERANGE, "gemm: an operand exceeds 2 GiB per batch element");
     }
     if (c_block < 0 || (c_block > 0 && (c_block_stride < (long)M * c_block || R)))
         return dfx::fail(DFX_EINVAL, "gemm: column-block-major C needs c_block_stride >= M * c_block and no residual");
