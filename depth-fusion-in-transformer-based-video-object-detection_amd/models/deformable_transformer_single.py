@@ -9,6 +9,8 @@ import math
 import torch
 from torch import nn
 
+from util.memo import memo_on
+
 from models.fused import Linear
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
@@ -125,9 +127,16 @@ class SpatialTransformerBase(nn.Module):
             shapes.append((f.shape[2], f.shape[3]))
             tok.append(f.flatten(2).transpose(1, 2))
             msk.append(m.flatten(1))
-            p = p.flatten(2).transpose(1, 2)
-            pos.append(p if level_embed is None else p + level_embed[lvl].view(1, 1, -1))
-        return torch.cat(tok, 1), torch.cat(msk, 1), torch.cat(pos, 1), shapes
+            if level_embed is None:
+                pos.append(p.flatten(2).transpose(1, 2))
+            else:
+                # positional embedding + level embedding: derived from the (memoised) positional tensor and the
+                # parameter's version, so inference builds it once per mask (util/memo.py)
+                pos.append(memo_on(p, ("lvl_pos", lvl, level_embed.data_ptr(), level_embed._version),
+                                   lambda p=p, lvl=lvl: p.flatten(2).transpose(1, 2) + level_embed[lvl].view(1, 1, -1)))
+        one = len(tok) == 1                     # a single level: nothing to concatenate (torch.cat would copy)
+        return (tok[0] if one else torch.cat(tok, 1), msk[0] if one else torch.cat(msk, 1),
+                pos[0] if one else torch.cat(pos, 1), shapes)
 
     def _spatial_stage(self, srcs, masks, pos_embeds, depth_srcs, depth_masks, depth_pos_embeds, query_embed,
                        rgbd_query=()):

@@ -77,13 +77,18 @@ class Bottleneck(nn.Module):
         operand rows allow (H*W a multiple of 4: every map of an 800x1333 frame), else the implicit-GEMM
         convolution (scalar gathers, any geometry) followed by the fused bias / residual / ReLU pass."""
         ho, wo = (x.shape[2] + stride - 1) // stride, (x.shape[3] + stride - 1) // stride
-        if (ho * wo) % 4 == 0:
+        if (ho * wo) % 4 == 0 and stride == 1:
             return _ops.conv1x1(x, w, b, residual=residual, relu=relu, stride=stride)
-        key = (w.data_ptr(), w._version)
+        # strided shortcut (the implicit GEMM gathers every other pixel itself: no subsampled copy of the map) and
+        # maps whose rows are not 16-byte aligned
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
         plans = self.__dict__.setdefault("_plans1x1", {})
+        fused = residual is None
         if slot not in plans or plans[slot][0] != key:
-            plans[slot] = (key, _ops.ConvPlan(w.reshape(w.shape[0], -1, 1, 1), None, stride, 0, 1, None))
-        return _ops.bias_act_(plans[slot][1](x), b, residual=residual, relu=relu)
+            plans[slot] = (key, _ops.ConvPlan(w.reshape(w.shape[0], -1, 1, 1), b if fused else None, stride, 0, 1,
+                                              "relu" if (fused and relu) else None))
+        y = plans[slot][1](x)
+        return y if fused else _ops.bias_act_(y, b, residual=residual, relu=relu)
 
     def forward(self, x):
         out = self.relu(self.bn1(self.conv1(x)))

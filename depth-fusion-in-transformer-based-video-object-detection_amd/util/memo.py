@@ -11,7 +11,7 @@ Disabled while autograd is recording.
 import torch
 
 _MEMO = {}
-_MAX = 24          # entries; the largest values are positional embeddings (~4 MB per frame)
+_MAX = 32          # entries; the largest values are positional embeddings (~4 MB per frame)
 
 
 def memo_on(t, tag, build):
@@ -20,10 +20,12 @@ def memo_on(t, tag, build):
     key = (id(t), tag)
     hit = _MEMO.get(key)
     if hit is not None and hit[0] is t and hit[1] == t._version:
+        _MEMO[key] = _MEMO.pop(key)             # most recently used last
         return hit[2]
     val = build()
-    if len(_MEMO) >= _MAX:
-        _MEMO.clear()
+    _MEMO.pop(key, None)
+    while len(_MEMO) >= _MAX:                   # evict the least recently used entry only: entries keyed on per-call
+        _MEMO.pop(next(iter(_MEMO)))            # tensors (valid ratios of one forward) must not flush the mask's
     _MEMO[key] = (t, t._version, val)
     return val
 
