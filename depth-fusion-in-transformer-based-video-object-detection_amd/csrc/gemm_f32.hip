@@ -392,6 +392,7 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
         if (force[0] == '3') return launch<64, 128, 1, 4, 32>(g, batch, b_is_kn, st);
         if (force[0] == '4') return launch<128, 128, 2, 2, 32>(g, batch, b_is_kn, st);
         if (force[0] == '5') return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
+        if (force[0] == '6') return launch<64, 64, 2, 2, 64>(g, batch, b_is_kn, st);
     }
     if (M <= 64) return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
     if (N <= 32) return launch<128, 32, 4, 1>(g, batch, b_is_kn, st);
@@ -414,6 +415,10 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     // 526 tiles of 64 x 128 = 3 on some CUs, 2.05 on average; 1052 of 64 x 64 = 5 against 4.1).
     auto fill = [](long tiles) { return (double)tiles / (256.0 * (double)((tiles + 255) / 256)); };
     const long t128 = (long)((M + 63) / 64) * ((N + 127) / 128) * zb, t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * zb;
+    // At most one 64 x 64 workgroup per CU (the 300-query layers of a small rank block: M = 1200, N = 256): nothing hides
+    // the global-load latency of a K-step but the step before it, so the K loop runs at ~1 us per step whatever its
+    // depth; 64-deep steps quarter their number (profiles/r02_rank_step.txt).
+    if (t64 <= 320 && K >= 128 && !getenv("DFX_GEMM_NO_DEEP")) return launch<64, 64, 2, 2, 64>(g, batch, b_is_kn, st);
     if (t128 < 8 * 256 && 0.95 * fill(t64) > fill(t128)) return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }
