@@ -55,7 +55,7 @@ __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: 
     return act == 1 ? fmaxf(v, 0.f) : 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
 }
 
-template <int BM, int BN, int WM, int WN, bool B_KN, int BK>
+template <int BM, int BN, int WM, int WN, bool B_KN, int BK, bool DMA>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
@@ -199,13 +199,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             rpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, o, 0, 0));
         }
     }
+    // ---- LDS-DMA staging (DMA = true: no A2 prologue, K a multiple of BK) -------------------------------------------
+    // The same LDS images, filled by `buffer_load_dwordx4 ... lds`: the data go from memory straight to LDS, so the
+    // VGPR -> LDS store traffic of a K-step (16 KB per workgroup at ~80 B/clk/CU, which delays the other waves' fragment
+    // reads: ablation in DESIGN.md, 125 -> 143 TFLOP/s without the stores) disappears, and so do the staging
+    // registers.  A wave-instruction fills 64 consecutive 16-byte slots; the images keep their padded pitch (5 slots per
+    // K-contiguous row, BN/4 + 1 per [k][n] row), the lane that falls on a pad slot re-loads its neighbour.  Per-lane
+    // byte offsets are loop-invariant, the K-step advances through the instruction's scalar offset; rows / columns
+    // outside the problem carry an offset beyond the extent and arrive as zeros.
+    constexpr int A_SLOTS = BM * (LDK / 4), B_PITCH = B_KN ? LDB / 4 : LDK / 4, B_SLOTS = (B_KN ? BK : BN) * B_PITCH;
+    constexpr int A_INSTR = (A_SLOTS + 63) / 64, B_INSTR = (B_SLOTS + 63) / 64;
+    constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned dva[DMA ? A_PW : 1], dvb[DMA ? B_PW : 1];
+    bool dpa[DMA ? A_PW : 1], dpb[DMA ? B_PW : 1];
+    if (DMA) {
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const int sl = (wave_u + 4 * i) * 64 + lane, row = sl / (LDK / 4), kq = min(sl % (LDK / 4), BK / 4 - 1), m = m0 + row;
+            dpa[i] = wave_u + 4 * i < A_INSTR && sl < A_SLOTS;
+            const unsigned o = g.ablk_stride > 0 ? ((unsigned)kq * (unsigned)g.ablk_stride + (unsigned)m * 4u) * 4u
+                                                 : ((unsigned)m * (unsigned)g.lda + (unsigned)kq * 4u) * 4u;
+            dva[i] = m < g.M ? o : kOut;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) {
+            const int sl = (wave_u + 4 * i) * 64 + lane;
+            dpb[i] = wave_u + 4 * i < B_INSTR && sl < B_SLOTS;
+            if (B_KN) {
+                const int kr = sl / B_PITCH, nq = min(sl % B_PITCH, BN / 4 - 1), n = n0 + nq * 4;
+                dvb[i] = n < g.N ? ((unsigned)kr * (unsigned)g.ldb + (unsigned)n) * 4u : kOut;
+            } else {
+                const int row = sl / B_PITCH, kq = min(sl % B_PITCH, BK / 4 - 1), n = n0 + row;
+                dvb[i] = n < g.N ? ((unsigned)n * (unsigned)g.ldb + (unsigned)kq * 4u) * 4u : kOut;
+            }
+        }
+    }
+    auto dma_tiles = [&](int k0, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass cannot form an LDS-address-space pointer; it only needs the kernel's handle)
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        const unsigned sa = g.ablk_stride > 0 ? (unsigned)(k0 >> 2) * (unsigned)g.ablk_stride * 4u : (unsigned)k0 * 4u;
+        const unsigned sb = B_KN ? (unsigned)k0 * (unsigned)g.ldb * 4u : (unsigned)k0 * 4u;
+        float *la = &As[buf][0][0], *lb = &Bs[buf][0];
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i)
+            if (dpa[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (wave_u + 4 * i) * 256), 16, dva[i], sa, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i)
+            if (dpb[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (wave_u + 4 * i) * 256), 16, dvb[i], sb, 0, 0);
+#endif
+    };
+
     const int steps = (K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
+    if (DMA) {
+        dma_tiles(0, 0);
+    } else {
+        load_tiles(0);
+        store_tiles(0);
+    }
     __syncthreads();
     for (int t = 0; t < steps; ++t) {
         const int buf = t & 1;
-        if (t + 1 < steps) load_tiles((t + 1) * BK);          // in flight during the MFMAs below
+        if (!DMA && t + 1 < steps) load_tiles((t + 1) * BK);   // in flight during the MFMAs below
         // A fragments (and B's for the [N][K] operand): one 16-byte read per lane per 4 MFMAs
         constexpr int KJ = BK / 8;
         float4 af[KJ][MT], bf[KJ][NT];
@@ -221,14 +276,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             }
         }
         float bs[2][NT];                                        // [K][N] operand: scalar reads, one MFMA ahead
-        if (B_KN) {
+        float bsa[DMA && B_KN ? BK / 2 : 1][NT];                // LDS-DMA staging: every fragment of the K-step up front
+        if (B_KN && !DMA) {
 #pragma unroll
             for (int jn = 0; jn < NT; ++jn) bs[0][jn] = Bs[buf][(half * 4) * LDB + wn * TN + jn * 32 + c];
+        }
+        if (DMA) {
+            // hipcc orders every LDS read that follows an LDS-DMA in program order behind it (s_waitcnt vmcnt(0): it
+            // cannot tell the two buffers of the one LDS array apart), so the K-step's reads all come first and the
+            // next tile's DMA is issued after them: it then lands under the 8 x MT x NT MFMAs below.
+            if (B_KN) {
+#pragma unroll
+                for (int q = 0; q < BK / 2; ++q)
+#pragma unroll
+                    for (int jn = 0; jn < NT; ++jn)
+                        bsa[q][jn] = Bs[buf][((q >> 2) * 8 + half * 4 + (q & 3)) * LDB + wn * TN + jn * 32 + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < steps) dma_tiles((t + 1) * BK, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int q = 0; q < BK / 2; ++q) {
             const int j = q >> 2, tt = q & 3, cur = q & 1, nxt = cur ^ 1;
-            if (B_KN && q + 1 < BK / 2) {
+            if (B_KN && !DMA && q + 1 < BK / 2) {
                 const int kn = ((q + 1) >> 2) * 8 + half * 4 + ((q + 1) & 3);
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) bs[nxt][jn] = Bs[buf][kn * LDB + wn * TN + jn * 32 + c];
@@ -241,15 +312,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                 const float av = tt == 0 ? af[j][i].x : tt == 1 ? af[j][i].y : tt == 2 ? af[j][i].z : af[j][i].w;
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) {
-                    const float bv = B_KN ? bs[cur][jn]
+                    const float bv = B_KN ? (DMA ? bsa[DMA ? q : 0][jn] : bs[cur][jn])
                                           : (tt == 0 ? bf[j][jn].x : tt == 1 ? bf[j][jn].y : tt == 2 ? bf[j][jn].z : bf[j][jn].w);
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (t + 1 < steps) store_tiles(buf ^ 1);
-        __syncthreads();
+        if (!DMA && t + 1 < steps) store_tiles(buf ^ 1);
+        __syncthreads();                                        // (waits for the LDS-DMA of the next tile as well)
     }
 
     // ---- epilogue ----
@@ -336,10 +407,17 @@ int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
     // or -2 (Linear), tag_b = tile
     const long flops = 2L * g.M * g.N * g.K * batch;
-    if (b_is_kn)
-        dfx::launch_timed(flops, -1, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, true, BK>, grid, block, 0, st, g);
-    else
-        dfx::launch_timed(flops, -2, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, false, BK>, grid, block, 0, st, g);
+    const int kloc = g.splits > 1 ? g.kper : g.K;
+    // LDS-DMA staging unless the prologue add needs registers, K has a tail, or the kernel is the HBM-bound short-K
+    // residual convolution (layer1 / layer2 conv3), where the DMA wait also drains the residual prefetch
+    bool dma = !g.A2 && g.K % BK == 0 && kloc % BK == 0 && !(g.R && kloc <= 128) && !getenv("DFX_GEMM_NO_DMA");
+    if (dma) {
+        if (b_is_kn) dfx::launch_timed(flops, -1, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, true, BK, true>, grid, block, 0, st, g);
+        else dfx::launch_timed(flops, -2, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, false, BK, true>, grid, block, 0, st, g);
+    } else {
+        if (b_is_kn) dfx::launch_timed(flops, -1, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, true, BK, false>, grid, block, 0, st, g);
+        else dfx::launch_timed(flops, -2, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, false, BK, false>, grid, block, 0, st, g);
+    }
     return dfx::check_launch("gemm_f32_kernel");
 }
 
