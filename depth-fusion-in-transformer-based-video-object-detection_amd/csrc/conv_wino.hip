@@ -146,22 +146,27 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
                 for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
 
     float xr[16];
-    f32x4 ur[U_LD];
-    auto load_chunk = [&](int ch) {
-        const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offsets
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // U chunk: memory -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, U_LD per wave): the
+    // staged image is lane-linear, so no registers and no ds_write are spent on the weights (half of the chunk's bytes)
+    auto dma_u = [&](int ch, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) void *lds_ptr;
         const unsigned us = ubase + (unsigned)ch * (kUChunk * 4u);
+        float *lu = Us + buf * UCH;
+#pragma unroll
+        for (int i = 0; i < U_LD; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr)(lu + (wave_u + 8 * i) * 256), 16, uoff[i], us, 0, 0);
+#endif
+    };
+    auto load_x = [&](int ch) {
+        const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offset
         if (xloader) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[i], xs, 0));
         }
-#pragma unroll
-        for (int i = 0; i < U_LD; ++i)
-            ur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff[i], us, 0));
     };
-    auto store_chunk = [&](int buf) {
-        float *us = Us + buf * UCH + tid * 4;
-#pragma unroll
-        for (int i = 0; i < U_LD; ++i) *reinterpret_cast<f32x4 *>(us + i * 2048) = ur[i];
+    auto store_v = [&](int buf) {
         if (!xloader) return;
         // B^T d B
         float dd[16], tm[16];
@@ -193,21 +198,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // chunk t, then load chunk t+2.  Either way chunk t+1 is complete at the barrier that ends iteration t, and the
     // buffer it goes to (that of chunk t-1) was released by the previous barrier.
     const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
-    load_chunk(0);
-    store_chunk(0);
-    if (late && g.nchunk > 1) load_chunk(1);
+    dma_u(0, 0);
+    load_x(0);
+    store_v(0);
+    if (late && g.nchunk > 1) load_x(1);
     __syncthreads();
     for (int ch = 0; ch < g.nchunk; ++ch) {
         const int buf = ch & 1;
-        if (!late) {
-            if (ch + 1 < g.nchunk) load_chunk(ch + 1);   // in flight during the MFMAs below
-        } else {
-            if (ch + 1 < g.nchunk) store_chunk(buf ^ 1);
-            if (ch + 2 < g.nchunk) load_chunk(ch + 2);
-        }
+        if (late && ch + 1 < g.nchunk) store_v(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        // operand fragments of both positions up front: the second position's LDS reads complete under the
-        // first position's MFMAs
+        // operand fragments of both positions up front (the second position's LDS reads complete under the first
+        // position's MFMAs), and BEFORE the next chunk's loads: hipcc orders every LDS access that follows an LDS-DMA in
+        // program order behind it (it cannot tell the two buffers apart), so the DMA is issued after the last read
         f32x4 af[2][CB];
         float bf[2][4][TB];
 #pragma unroll
@@ -221,6 +223,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int j = 0; j < TB; ++j) bf[p][tt][j] = vb[tt * TW + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < g.nchunk) dma_u(ch + 1, buf ^ 1);           // lands under the MFMAs below
+        if (!late) {
+            if (ch + 1 < g.nchunk) load_x(ch + 1);
+        } else {
+            if (ch + 2 < g.nchunk) load_x(ch + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -237,8 +246,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!late && ch + 1 < g.nchunk) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (!late && ch + 1 < g.nchunk) store_v(buf ^ 1);
+        __syncthreads();                            // (waits for the U chunk's DMA as well)
     }
 
     // ---- epilogue: meet in LDS, A^T M A, bias, activation ----
