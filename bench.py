@@ -63,7 +63,7 @@ torch.backends.cudnn.allow_tf32 = False
 MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
 # fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
 # family's launches per step, from the PMC passes over this workload committed in profiles/r02_pmc_traffic.md
-FAMILY_TRAFFIC_PER_STEP = {"gemm": (206167.2e6, 214), "wino": (18843.8e6, 28), "igemm": (20166.1e6, 7)}
+FAMILY_TRAFFIC_PER_STEP = {"gemm": (197789.0e6, 212), "wino": (18836.2e6, 28), "igemm": (33042.7e6, 9)}
 
 # per-frame algorithmic work of config E (all-current mode)
 BYTES_PER_FRAME = 4.333e9
