@@ -29,6 +29,7 @@
 // the first iteration.  Levels that do not fit (more than ~5100 bordered tokens) and launches
 // with few queries per frame (decoder cross-attention, Lq = 300) stay on msda_fused.hip.
 #include "dfx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -160,56 +161,32 @@ struct LevelArgs {
     const float *value, *ref, *off, *logits;
     float *out;
     dfx_msda_level_layout ly;
-    int H, W, Lq, PL, qsplit;
+    int H, W, Lq, PL, qsplit, nitems;
 };
 
+// Persistent: the grid is at most one workgroup per CU (146 KB of LDS each) and every workgroup walks the items
+// (frame, head, octet, query slice) b, b + grid, b + 2 grid, ...: workgroup launch, index setup and the zero border are
+// paid once per CU instead of once per item (4 items per CU at 32 frames).
 template <int REFDIM>
 __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
 {
     const int H = g.H, W = g.W, Lq = g.Lq, PL = g.PL, qsplit = g.qsplit;
     extern __shared__ float4 img[];                 // [2 planes][PL bordered tokens]
     const int tid = threadIdx.x;
-    // block -> (frame, head, octet, query slice).  Blocks go round-robin to the 8 XCDs, so the low
-    // 3 bits pick the head: the 4 octets (and the query slices) of one (frame, head) share an L2.
-    const int head = blockIdx.x & 7;
-    const int r = blockIdx.x >> 3;
-    const int per = 4 * qsplit;
-    const int n = r / per, sub = r - n * per;
-    const int oct = sub & 3, qs = sub >> 2;
     const int S = H * W, WB = W + 2;
+    const int per = 4 * qsplit;
     const int qper = (Lq + qsplit - 1) / qsplit;
-    const int qbeg = qs * qper, qend = min(Lq, qbeg + qper);
     Level lv;
     lv.size = (v2f){(float)W, (float)H};
     lv.rsize = (v2f){1.f / (float)W, 1.f / (float)H};
     lv.H = H; lv.W = W; lv.WB = WB;
-
-    // ---- issue the staging loads: lane pair = (token, chunk), 32 contiguous bytes per token ----
-    const float *__restrict__ vb = g.value + n * g.ly.value_frame + head * g.ly.value_head + oct * g.ly.value_oct;
     const long vs_token = g.ly.value_token, vs_chunk = g.ly.value_chunk;
-    float4 v[STAGE_PASSES];
-    const int t0 = tid >> 1, c0 = tid & 1;                  // pass u handles token t0 + u * THREADS / 2
-    {
-        const float *src = vb + t0 * vs_token + c0 * vs_chunk;
-        const long step = (THREADS / 2) * vs_token;
-#pragma unroll
-        for (int u = 0; u < STAGE_PASSES; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // straight-line, per-lane predicated: all loads in flight at once
-            if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
-        }
-    }
-    // ---- parameters of the first query ----
     const long off_stride = g.ly.off_row, logit_stride = g.ly.logit_row;
-    const float *__restrict__ refn = g.ref + (long)n * Lq * REFDIM;
-    const float *__restrict__ offn = g.off + (long)n * Lq * off_stride + head * g.ly.off_head;
-    const float *__restrict__ lgn = g.logits + (long)n * Lq * logit_stride + head * g.ly.logit_head;
-    float *__restrict__ outn = g.out + (long)n * Lq * g.ly.out_row + head * g.ly.out_head + oct * g.ly.out_oct;
     const long out_row = g.ly.out_row, out_chunk = g.ly.out_chunk;
-    int q = qbeg + tid;
-    bool have = q < qend;
-    Raw raw;
-    if (have) raw = load_raw<REFDIM>(refn + (long)q * REFDIM, offn + q * off_stride, lgn + q * logit_stride);
-    // ---- zero border: rows 0, H+1, H+2 and columns 0, W+1 of rows 1..H, both planes ----
+    const int t0 = tid >> 1, c0 = tid & 1;          // staging: lane pair = (token, chunk); pass u handles token t0 + u * THREADS / 2
+    const float4 *org = img + WB + 1;               // token (y, x) = (0, 0) of the map inside the bordered image
+
+    // ---- zero border (once: staging only ever writes the interior): rows 0, H+1, H+2 and columns 0, W+1 of rows 1..H ----
     {
         const int nb = 3 * WB + 2 * H + 1;          // + the token after the last row: (y1, x1) of a sample at (H, W)
         for (int j = tid; j < 2 * nb; j += THREADS) {
@@ -222,50 +199,80 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
             img[c * PL + tb] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    // ---- taps of the first query while the value loads fly ----
-    Taps tp;
-    if (have) tp = make_taps<REFDIM>(raw, lv);
-    // ---- land the level in LDS: (y, x) of the pass's token advance by a constant step, no division ----
-    {
-        const int dy = (THREADS / 2) / W, dx = (THREADS / 2) - dy * W;
-        int y = t0 / W, x = t0 - y * W;
-        int idx = c0 * PL + (y + 1) * WB + x + 1;
-#pragma unroll
-        for (int u = 0; u < STAGE_PASSES; ++u) {
-            if (t0 + u * (THREADS / 2) < S) img[idx] = v[u];
-            x += dx;
-            idx += dy * WB + dx;
-            if (x >= W) { x -= W; idx += 2; }
-        }
-    }
-    __syncthreads();
+    // item -> (frame, head, octet, query slice).  Items go round-robin to the workgroups and the grid is a multiple of 8
+    // (or the item count), so the low 3 bits - the head - are fixed per workgroup and the 4 octets (and the query
+    // slices) of one (frame, head) stay on one XCD / L2.
+    for (int item = blockIdx.x; item < g.nitems; item += gridDim.x) {
+        const int head = item & 7, r = item >> 3;
+        const int n = r / per, sub = r - n * per;
+        const int oct = sub & 3, qs = sub >> 2;
+        const int qbeg = qs * qper, qend = min(Lq, qbeg + qper);
 
-    // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters load meanwhile ----
-    const float4 *org = img + WB + 1;               // token (y, x) = (0, 0) of the map inside the bordered image
-    while (have) {
-        const int qn = q + THREADS;
-        const bool hn = qn < qend;
-        if (hn) raw = load_raw<REFDIM>(refn + (long)qn * REFDIM, offn + qn * off_stride, lgn + qn * logit_stride);
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        // ---- issue the staging loads: lane pair = (token, chunk), 32 contiguous bytes per token ----
+        const float *__restrict__ vb = g.value + n * g.ly.value_frame + head * g.ly.value_head + oct * g.ly.value_oct;
+        float4 v[STAGE_PASSES];
+        {
+            const float *src = vb + t0 * vs_token + c0 * vs_chunk;
+            const long step = (THREADS / 2) * vs_token;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float4 *b0 = org + tp.tb[p];
-            const float4 *b1 = b0 + PL;
-            fma4(a0, tp.wt[p].x, b0[0]);
-            fma4(a1, tp.wt[p].x, b1[0]);
-            fma4(a0, tp.wt[p].y, b0[1]);
-            fma4(a1, tp.wt[p].y, b1[1]);
-            fma4(a0, tp.wb[p].x, b0[WB]);
-            fma4(a1, tp.wb[p].x, b1[WB]);
-            fma4(a0, tp.wb[p].y, b0[WB + 1]);
-            fma4(a1, tp.wb[p].y, b1[WB + 1]);
+            for (int u = 0; u < STAGE_PASSES; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // straight-line, per-lane predicated: all loads in flight at once
+                if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
+            }
         }
-        float *dst = outn + q * out_row;
-        *reinterpret_cast<float4 *>(dst) = a0;
-        *reinterpret_cast<float4 *>(dst + out_chunk) = a1;
-        if (hn) tp = make_taps<REFDIM>(raw, lv);
-        q = qn;
-        have = hn;
+        // ---- parameters and taps of the first query while the value loads fly ----
+        const float *__restrict__ refn = g.ref + (long)n * Lq * REFDIM;
+        const float *__restrict__ offn = g.off + (long)n * Lq * off_stride + head * g.ly.off_head;
+        const float *__restrict__ lgn = g.logits + (long)n * Lq * logit_stride + head * g.ly.logit_head;
+        float *__restrict__ outn = g.out + (long)n * Lq * g.ly.out_row + head * g.ly.out_head + oct * g.ly.out_oct;
+        int q = qbeg + tid;
+        bool have = q < qend;
+        Raw raw;
+        if (have) raw = load_raw<REFDIM>(refn + (long)q * REFDIM, offn + q * off_stride, lgn + q * logit_stride);
+        Taps tp;
+        if (have) tp = make_taps<REFDIM>(raw, lv);
+        // ---- land the level in LDS: (y, x) of the pass's token advance by a constant step, no division ----
+        {
+            const int dy = (THREADS / 2) / W, dx = (THREADS / 2) - dy * W;
+            int y = t0 / W, x = t0 - y * W;
+            int idx = c0 * PL + (y + 1) * WB + x + 1;
+#pragma unroll
+            for (int u = 0; u < STAGE_PASSES; ++u) {
+                if (t0 + u * (THREADS / 2) < S) img[idx] = v[u];
+                x += dx;
+                idx += dy * WB + dx;
+                if (x >= W) { x -= W; idx += 2; }
+            }
+        }
+        __syncthreads();
+
+        // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters load meanwhile ----
+        while (have) {
+            const int qn = q + THREADS;
+            const bool hn = qn < qend;
+            if (hn) raw = load_raw<REFDIM>(refn + (long)qn * REFDIM, offn + qn * off_stride, lgn + qn * logit_stride);
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 *b0 = org + tp.tb[p];
+                const float4 *b1 = b0 + PL;
+                fma4(a0, tp.wt[p].x, b0[0]);
+                fma4(a1, tp.wt[p].x, b1[0]);
+                fma4(a0, tp.wt[p].y, b0[1]);
+                fma4(a1, tp.wt[p].y, b1[1]);
+                fma4(a0, tp.wb[p].x, b0[WB]);
+                fma4(a1, tp.wb[p].x, b1[WB]);
+                fma4(a0, tp.wb[p].y, b0[WB + 1]);
+                fma4(a1, tp.wb[p].y, b1[WB + 1]);
+            }
+            float *dst = outn + q * out_row;
+            *reinterpret_cast<float4 *>(dst) = a0;
+            *reinterpret_cast<float4 *>(dst + out_chunk) = a1;
+            if (hn) tp = make_taps<REFDIM>(raw, lv);
+            q = qn;
+            have = hn;
+        }
+        __syncthreads();                            // every gather of this item is done before the next level lands
     }
 }
 
@@ -329,12 +336,20 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
         raised = true;
     }
     const int S = H * W;
-    const LevelArgs g{value, ref, off, logits, out, ly, H, W, Lq, PL, qsplit};
+    const LevelArgs g{value, ref, off, logits, out, ly, H, W, Lq, PL, qsplit, (int)blocks};
+    // persistent: at most one workgroup per CU, a multiple of 8 so that item & 7 (the head) is fixed per workgroup
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        ncu = n / 8 * 8;
+    }
+    const long grid = (blocks < ncu || getenv("DFX_LEVEL_NOT_PERSISTENT")) ? blocks : ncu;
     // algorithmic bytes of this launch: value + (offsets, logits) + out, fp32
     const long bytes = 4L * ((long)N * S * 256 + 3L * N * Lq * 8 * 4 + (long)N * Lq * 256);
     if (ref_dim == 2)
-        dfx::launch_timed(bytes, Lq, S, msda_fused_level<2>, dim3((unsigned)blocks), dim3(THREADS), lds, st, g);
+        dfx::launch_timed(bytes, Lq, S, msda_fused_level<2>, dim3((unsigned)grid), dim3(THREADS), lds, st, g);
     else
-        dfx::launch_timed(bytes, Lq, S, msda_fused_level<4>, dim3((unsigned)blocks), dim3(THREADS), lds, st, g);
+        dfx::launch_timed(bytes, Lq, S, msda_fused_level<4>, dim3((unsigned)grid), dim3(THREADS), lds, st, g);
     return dfx::check_launch("msda_fused_level");
 }
