@@ -157,6 +157,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 #pragma unroll
         for (int i = 0; i < U_LD; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr)(lu + (wave_u + 8 * i) * 256), 16, uoff[i], us, 0, 0);
+#else
+        (void)urs; (void)ubase; (void)wave_u; (void)ch; (void)buf;
 #endif
     };
     auto load_x = [&](int ch) {
