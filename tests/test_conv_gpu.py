@@ -107,3 +107,31 @@ def test_igemm_reads_a_channel_slice_in_place():
         w = torch.randn(16, ci, 3, 3, generator=g).cuda()
         plan = ops.ConvPlan(w, None, 2, 1, 1, None)
         assert torch.equal(plan(x[:, sl]), plan(x[:, sl].contiguous()))
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,dil", [(64, 64, 200, 334, 1), (128, 128, 100, 167, 1), (512, 512, 50, 84, 2)])
+def test_convolutions_at_production_sizes_agree_and_are_linear(Ci, Co, H, W, dil):
+    """The ResNet maps of an 800x1333 frame: the two algorithms against each other (different arithmetic, same
+    convolution) and linearity conv(a x + y) = a conv(x) + conv(y) of each - size-independent checks where an fp64
+    reference of the whole map would take minutes on the host."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(Ci + H)
+    x = torch.randn(2, Ci, H, W, generator=g).cuda()
+    y = torch.randn(2, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).cuda()
+    wino = ops.ConvPlan(w, None, 1, dil, dil, None, algo="wino")
+    igemm = ops.ConvPlan(w, None, 1, dil, dil, None, algo="igemm")
+    a, b = wino(x), igemm(x)
+    assert (a - b).abs().max().item() < 3e-5
+    for plan in (wino, igemm):
+        lhs = plan(2.5 * x + y)
+        rhs = 2.5 * plan(x) + plan(y)
+        assert (lhs - rhs).abs().max().item() < 2e-4          # outputs of magnitude ~10, three roundings of K = 9 Ci sums
+    # a one-hot input reproduces the (flipped) filter taps around the pixel: exact placement of every tap, incl. dilation
+    e = torch.zeros(1, Ci, H, W).cuda()
+    e[0, 3, H // 2, W // 2] = 1.0
+    out = wino(e)
+    for ky in range(3):
+        for kx in range(3):
+            got = out[0, :, H // 2 - (ky - 1) * dil, W // 2 - (kx - 1) * dil]
+            assert (got - w[:, 3, ky, kx]).abs().max().item() < 1e-6
