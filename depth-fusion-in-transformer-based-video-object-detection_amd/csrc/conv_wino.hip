@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     dma_u(0, 0);
     load_x(0);
     store_v(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (late && g.nchunk > 1) load_x(1);
     __syncthreads();
     for (int ch = 0; ch < g.nchunk; ++ch) {
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!late && ch + 1 < g.nchunk) store_v(buf ^ 1);
-        __syncthreads();                            // (waits for the U chunk's DMA as well)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the U chunk have landed ...
+        __syncthreads();                            // ... and after the barrier so have everybody's
     }
 
     // ---- epilogue: meet in LDS, A^T M A, bias, activation ----

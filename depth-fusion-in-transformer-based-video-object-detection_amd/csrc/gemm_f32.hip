@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const int steps = (K + BK - 1) / BK;
     if (DMA) {
         dma_tiles(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         load_tiles(0);
         store_tiles(0);
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!DMA && t + 1 < steps) store_tiles(buf ^ 1);
-        __syncthreads();                                        // (waits for the LDS-DMA of the next tile as well)
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next tile have landed ...
+        __syncthreads();                                        // ... and after the barrier so have everybody's
     }
 
     // ---- epilogue ----
