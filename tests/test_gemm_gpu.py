@@ -225,3 +225,29 @@ def test_group_norm_matches_torch(N, C, H, W):
     assert (a.double() - want).abs().max().item() < 2e-5
     assert b.shape == x.shape and torch.equal(b.contiguous(), a)
     assert b.flatten(2).transpose(1, 2).is_contiguous()       # what the transformer does next is free
+
+
+def test_lds_dma_staging_is_bit_identical_to_register_staging_repeatedly(monkeypatch):
+    """The LDS-DMA staged kernel (default) against the register-staged one (DFX_GEMM_NO_DMA=1) on the same operands,
+    many launches per shape: identical bits every time - a landing-order race would show up as a stray tile."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(77)
+    for kind, shape in (("linear", (33600, 256, 1024)), ("linear", (4200, 1024, 256)), ("linear", (1200, 256, 256)),
+                        ("conv", (4, 1024, 2048, 50, 84)), ("conv", (2, 256, 64, 200, 334))):
+        if kind == "linear":
+            M, N, K = shape
+            x = torch.randn(M, K, generator=g).cuda()
+            w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            run = lambda: ops.linear(x, w, b, relu=True)
+        else:
+            Nb, Ci, Co, H, W = shape
+            x = torch.randn(Nb, Ci, H, W, generator=g).cuda()
+            w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda()
+            b = torch.randn(Co, generator=g).cuda()
+            run = lambda: ops.conv1x1(x, w, b, relu=True)
+        monkeypatch.setenv("DFX_GEMM_NO_DMA", "1")
+        ref = run()
+        monkeypatch.delenv("DFX_GEMM_NO_DMA")
+        for _ in range(25):
+            assert torch.equal(run(), ref), (kind, shape)
