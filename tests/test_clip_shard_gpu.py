@@ -142,3 +142,22 @@ def test_bench_py_two_ranks_gloo_rehearsal(tmp_path):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["frames_per_gpu"] == 2 and line["roofline"]["bound"] == "mfma"
+
+
+def test_clip_outputs_are_run_to_run_deterministic():
+    """No library solver is left in the inference path (round 2), and no kernel of it accumulates with atomics: the same
+    clip gives the same bits run after run, default settings (no cudnn.deterministic)."""
+    from models.clip_inference import ClipRunner
+    saved = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = False
+    try:
+        runner = ClipRunner(_build(), micro_batch=4)
+        clip = _clip().cuda()
+        first = runner(clip)
+        for _ in range(3):
+            again = runner(clip)
+            assert torch.equal(first["pred_logits"], again["pred_logits"]) and torch.equal(first["pred_boxes"], again["pred_boxes"])
+            for a, b in zip(first["topk"], again["topk"]):
+                assert torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.deterministic = saved
