@@ -175,12 +175,12 @@ def main():
                          "clip at a time on one stream; 1 = on for a single GPU - the default; the per-kernel roofline "
                          "durations then come from one extra single-stream step; 2 = on for N > 1 as well)")
     ap.add_argument("--deterministic", type=int, default=0,
-                    help="ask MIOpen for run-to-run deterministic convolution solvers (costs ~6 %% here)")
+                    help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank "
                          "code path with several ranks on one GPU)")
     ap.add_argument("--conv-autotune", type=int, default=0,
-                    help="let MIOpen time its fp32 solvers per convolution shape during warm-up (cudnn.benchmark)")
+                    help="(no-op since round 2: no library convolution is left in the path)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
