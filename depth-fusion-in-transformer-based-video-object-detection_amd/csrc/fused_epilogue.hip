@@ -102,38 +102,42 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool(const float *__restrict
                                                          float *__restrict__ out, int C, int H, int W, int Ho, int Wo,
                                                          long rows)
 {
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    // items = (output row, group of 4 output columns), one per thread, so that every lane of a workgroup works whatever
+    // the row width (a 334-wide row has 84 groups: a workgroup per row left two thirds of its lanes idle)
+    const int Q = (Wo + 3) / 4;
+    const long items = rows * Q;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+        const long row = it / Q;
+        const int ox = (int)(it - row * Q) * 4;
         const int oy = (int)(row % Ho);
         const long plane = row / Ho;
         const float b = bias[plane % C];
         const float *src = x + plane * H * W;
         const int y0 = oy * 2 - 1;
-        for (int ox = threadIdx.x * 4; ox < Wo; ox += blockDim.x * 4) {
-            const int xl = ox * 2 - 1;                       // leftmost input column (may be -1)
-            float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const int xl = ox * 2 - 1;                       // leftmost input column (may be -1)
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = y0 + dy;
-                if (yy < 0 || yy >= H) continue;
-                const float *r = src + (long)yy * W;
-                float v[9];
-                v[0] = xl >= 0 ? r[xl] : -INFINITY;
-                if (xl + 8 < W) {                            // columns xl+1 .. xl+8 all inside the row
-                    const float4 p = *reinterpret_cast<const float4 *>(r + xl + 1);
-                    const float4 q = *reinterpret_cast<const float4 *>(r + xl + 5);
-                    v[1] = p.x; v[2] = p.y; v[3] = p.z; v[4] = p.w; v[5] = q.x; v[6] = q.y; v[7] = q.z; v[8] = q.w;
-                } else {
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y0 + dy;
+            if (yy < 0 || yy >= H) continue;
+            const float *r = src + (long)yy * W;
+            float v[9];
+            v[0] = xl >= 0 ? r[xl] : -INFINITY;
+            if (xl + 8 < W) {                            // columns xl+1 .. xl+8 all inside the row
+                const float4 p = *reinterpret_cast<const float4 *>(r + xl + 1);
+                const float4 q = *reinterpret_cast<const float4 *>(r + xl + 5);
+                v[1] = p.x; v[2] = p.y; v[3] = p.z; v[4] = p.w; v[5] = q.x; v[6] = q.y; v[7] = q.z; v[8] = q.w;
+            } else {
 #pragma unroll
-                    for (int k = 1; k < 9; ++k) v[k] = xl + k < W ? r[xl + k] : -INFINITY;
-                }
-#pragma unroll
-                for (int o = 0; o < 4; ++o) m[o] = fmaxf(m[o], fmaxf(fmaxf(v[2 * o], v[2 * o + 1]), v[2 * o + 2]));
+                for (int k = 1; k < 9; ++k) v[k] = xl + k < W ? r[xl + k] : -INFINITY;
             }
-            float *dst = out + row * Wo + ox;
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                if (ox + o < Wo) dst[o] = fmaxf(m[o] + b, 0.f);
+            for (int o = 0; o < 4; ++o) m[o] = fmaxf(m[o], fmaxf(fmaxf(v[2 * o], v[2 * o + 1]), v[2 * o + 2]));
         }
+        float *dst = out + row * Wo + ox;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (ox + o < Wo) dst[o] = fmaxf(m[o] + b, 0.f);
     }
 }
 
@@ -147,7 +151,8 @@ extern "C" int dfx_bias_relu_maxpool_f32(const float *x, const float *bias, floa
     if (!x || !bias || !out) return dfx::fail(DFX_EINVAL, "bias_relu_maxpool: null pointer");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;          // floor((H + 2 - 3) / 2) + 1
     const long rows = (long)N * C * Ho;
-    const unsigned grid = (unsigned)(rows < (1L << 20) ? rows : (1L << 20));
+    const long blocks = (rows * ((Wo + 3) / 4) + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < (1L << 20) ? blocks : (1L << 20));
     hipLaunchKernelGGL(bias_relu_maxpool, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, out, C, H,
                        W, Ho, Wo, rows);
     return dfx::check_launch("bias_relu_maxpool");
