@@ -251,3 +251,43 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging_repeatedly(monkeyp
         monkeypatch.delenv("DFX_GEMM_NO_DMA")
         for _ in range(25):
             assert torch.equal(run(), ref), (kind, shape)
+
+
+def test_linear_fuzz_shapes_match_fp64():
+    """Random small shapes: every tile family, K with and without a 16-tail (LDS-DMA / register staging), N not a
+    multiple of 4 (narrow epilogue), with / without bias, residual, prologue add and row mask."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(2024)
+    for trial in range(40):
+        M = int(torch.randint(1, 700, (1,), generator=g))
+        N = int(torch.randint(1, 300, (1,), generator=g))
+        K = int(torch.randint(1, 137, (1,), generator=g)) * 4
+        flags = torch.randint(0, 2, (5,), generator=g).tolist()
+        x = torch.randn(M, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        b = torch.randn(N, generator=g).cuda() if flags[0] else None
+        res = torch.randn(M, N, generator=g).cuda() if flags[1] else None
+        add = torch.randn(M, K, generator=g).cuda() if flags[2] else None
+        mask = (torch.rand(M, generator=g) > 0.7).cuda() if flags[3] else None
+        got = ops.linear(x, w, b, relu=bool(flags[4]), residual=res, add=add, row_mask=mask)
+        want = _ref_linear(x, w, b, bool(flags[4]), res, add, mask)
+        err = (got.double() - want).abs().max().item()
+        assert err < 6e-6 * K ** 0.5 * (2.0 if add is not None else 1.0), (trial, M, N, K, flags, err)
+
+
+def test_conv1x1_fuzz_shapes_match_fp64():
+    from dfx import ops
+    g = torch.Generator().manual_seed(7)
+    for trial in range(20):
+        Nb = int(torch.randint(1, 4, (1,), generator=g))
+        Ci = int(torch.randint(1, 40, (1,), generator=g)) * 4
+        Co = int(torch.randint(1, 200, (1,), generator=g))
+        H = int(torch.randint(1, 12, (1,), generator=g)) * 2
+        W = int(torch.randint(1, 12, (1,), generator=g)) * 2
+        x = torch.randn(Nb, Ci, H, W, generator=g).cuda()
+        w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda()
+        b = torch.randn(Co, generator=g).cuda()
+        r = torch.randn(Nb, Co, H, W, generator=g).cuda()
+        want = (torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double()).relu()
+        got = ops.conv1x1(x, w, b, residual=r, relu=True)
+        assert (got.double() - want).abs().max().item() < 6e-6 * Ci ** 0.5, (trial, Nb, Ci, Co, H, W)
