@@ -46,15 +46,18 @@ int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const
  * way out.  2.25x fewer multiplications than the direct form.  A dilated convolution (the DC5 stage,
  * dilation 2) is the same computation on the dilation x dilation interleaved sub-lattices of the map.
  *
- *   x   [N, Ci, H, W]       Ci a multiple of 8
- *   u   [16, Co, Ci]        transformed weights  U = G g G^T  (dfx_wino_weights_f32)
+ *   x   [N, Ci, H, W]       Ci a multiple of 8, N*Ci*H*W < 2^30
+ *   u   16*Co*Ci floats     transformed weights  U = G g G^T, 16-byte aligned, in the blocked order the kernel
+ *                           stages them - opaque to the caller, produced only by dfx_wino_weights_f32;
+ *                           Co a multiple of 64
  *   y   [N, Co, H, W]       y = act(conv + bias[co])
  */
 int dfx_conv3x3_wino_f32(const float *x, const float *u, const float *bias, float *y,
                          int N, int Ci, int H, int W, int Co, int dilation, int act, void *stream);
 
 /* w [Co, Ci, 3, 3] (optionally scaled per output channel by scale[Co], the folded FrozenBatchNorm2d
- * weight * rsqrt(var + eps)) -> u [16, Co, Ci] */
+ * weight * rsqrt(var + eps)) -> u, 16*Co*Ci floats in the kernel's staging order
+ * [Co/64][Ci/8][16 positions][2][64 co][4 ci];  Ci a multiple of 8, Co of 64 */
 int dfx_wino_weights_f32(const float *w, const float *scale, float *u, int Co, int Ci, void *stream);
 
 #ifdef __cplusplus
