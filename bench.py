@@ -4,12 +4,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[4], SURVEY.md 8d "config E"): one synthetic 32-frame RGB-D clip,
-frames [32,4,800,1333] ~ N(0,1) (seed 42), no padding, every frame gets an output with the other
-31 frames as its reference frames ("all-current" mode, models/clip_inference.py).  Weights are each
-module's own initialisation under seed 42 (no checkpoints exist offline).  The clip is FIXED and
-its frames are sharded in contiguous blocks over the N ranks (strong scaling): one rank per GPU,
-one RCCL all-gather of the per-frame reference query sets per step.  A step = the whole clip.
+Workload (BASELINE.json configs[4], SURVEY.md 8d "config E"): synthetic 32-frame RGB-D clips,
+frames [32,4,800,1333] ~ N(0,1) (clip c: seed 42 + c), no padding, every frame gets an output with the other
+31 frames of its clip as its reference frames ("all-current" mode, models/clip_inference.py).  Weights are each
+module's own initialisation under seed 42 (no checkpoints exist offline).  Every clip is sharded in contiguous
+blocks of 32/N frames over the N ranks (4 frames per GPU at N = 8), one rank per GPU, and the per-frame reference
+query sets are exchanged with one RCCL all-gather per step.  A step serves --clips-per-step clips at once
+(default: N, so a rank handles 32 frames per step whatever N is - weak scaling, the throughput mode of a stream
+of clips; one clip per step at N = 1).  --clips-per-step 1 is the latency mode: one clip in flight, each rank
+runs only its 32/N frames per step (strong scaling; its kernels are small at N = 8, tools/rank_step.py).
 Inputs are resident in HBM before the timed region.  Compute type fp32 throughout.
 
 Every MSDeformAttn's sampling_offsets.weight (zero at initialisation, so that all queries would share one offset
@@ -159,6 +162,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="clip length T (fixed across N)")
+    ap.add_argument("--clips-per-step", type=int, default=0,
+                    help="clips served per step, each sharded over the N ranks (0 = N: every rank runs T frames per step, "
+                         "weak scaling; 1 = one clip in flight, T/N frames per rank and step, strong scaling)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--micro-batch", type=int, default=32,
@@ -208,15 +214,22 @@ def main():
     from models.clip_inference import ClipRunner
     _lib.load()                                                     # fail loudly without the HIP library
     model = build(device, a.frames - 1)
-    clip = torch.randn(a.frames, 4, a.height, a.width, generator=torch.Generator().manual_seed(42))
-    mine = clip[rank * per_rank:(rank + 1) * per_rank].to(device)   # resident in HBM before timing
-    runner = ClipRunner(model, micro_batch=min(a.micro_batch, per_rank), overlap=bool(a.overlap))
-    n_micro = -(-per_rank // min(a.micro_batch, per_rank))
+    clips = a.clips_per_step if a.clips_per_step > 0 else world
+    block = []                                                      # this rank's frames of every clip, clip-major
+    for c in range(clips):
+        clip = torch.randn(a.frames, 4, a.height, a.width, generator=torch.Generator().manual_seed(42 + c))
+        block.append(clip[rank * per_rank:(rank + 1) * per_rank].to(device))
+        del clip
+    mine = torch.cat(block, 0) if clips > 1 else block[0]          # resident in HBM before timing
+    del block
+    rank_frames = clips * per_rank                                  # frames a rank runs per step
+    runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap))
+    n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
     # N > 1: the exchange would sit on the side stream; that is how torch.distributed's NCCL backend is meant to be
     # used, but it could not be exercised on RCCL in this round (one GPU per session), so it needs --pipeline 2
     pipelined = n_micro == 1 and (a.pipeline >= 2 or (a.pipeline == 1 and world == 1))
-    step = (lambda: runner.submit(mine)) if pipelined else (lambda: runner(mine))
+    step = (lambda: runner.submit(mine, clips=clips)) if pipelined else (lambda: runner(mine, clips=clips))
 
     def barrier():
         if world > 1:
@@ -244,21 +257,36 @@ def main():
         # single-stream step (same inputs, same kernels) after the timed region; both are reported.
         timed_region_launches = launches
         saved_overlap, runner.overlap = runner.overlap, False
-        runner(mine)
+        runner(mine, clips=clips)
         barrier()
         ops.profile_start()
-        runner(mine)
+        runner(mine, clips=clips)
         barrier()
         launches = ops.profile_stop()
         runner.overlap = saved_overlap
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    # latency mode beside the throughput number: ONE clip in flight, each rank runs only its T/N frames per step
+    dt_single = None
+    if world > 1 and clips > 1:
+        one = mine[:per_rank]                                      # the rank's block of clip 0
+        for _ in range(max(1, a.warmup)):
+            runner(one)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            runner(one)
+        barrier()
+        dt_single = time.perf_counter() - t1
+
+    t = torch.tensor([dt, dt_single or 0.0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    if dt_single is not None:
+        dt_single = float(t[1].item())
 
     if rank == 0:
-        fps = a.frames * a.steps / dt
+        fps = clips * a.frames * a.steps / dt
         steps_profiled = a.steps if timed_region_launches is None else 1
         step_s = dt / a.steps
         fam = {-1: ("gemm_f32_kernel, [K,N] operand (1x1 convolutions of the backbones / input_proj)", "mfma"),
@@ -275,7 +303,7 @@ def main():
             tr_key = {-3: "wino", -4: "igemm"}.get(tag)
             traffic = None
             if tr_key and a.frames == 32 and a.height == 800 and a.width == 1333:      # per launch, scaled to the rank's frames
-                traffic = int(FAMILY_TRAFFIC_PER_STEP[tr_key][0] / FAMILY_TRAFFIC_PER_STEP[tr_key][1] * per_rank / 32)
+                traffic = int(FAMILY_TRAFFIC_PER_STEP[tr_key][0] / FAMILY_TRAFFIC_PER_STEP[tr_key][1] * rank_frames / 32)
             kernels.append({"kernel": name, "bound": bound, "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12,
                             "unit": "TFLOP/s", "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4), "traffic": traffic,
                             "launches_per_step": round(len(rec) / steps_profiled, 1),
@@ -289,7 +317,7 @@ def main():
                                                "with the largest share of GPU time)",
                     "achieved": round(wsum / tsum / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": round(wsum / tsum / FP32_MFMA_PEAK, 4),
-                    "traffic": (int(FAMILY_TRAFFIC_PER_STEP["gemm"][0] / FAMILY_TRAFFIC_PER_STEP["gemm"][1] * per_rank / 32)
+                    "traffic": (int(FAMILY_TRAFFIC_PER_STEP["gemm"][0] / FAMILY_TRAFFIC_PER_STEP["gemm"][1] * rank_frames / 32)
                                 if a.frames == 32 and a.height == 800 and a.width == 1333 else None),
                     "traffic_source": "PMC 2 x FETCH_SIZE + WRITE_SIZE (HBM + Infinity Cache side of L2), average per launch of "
                                       "the family, profiles/r02_pmc_traffic.md",
@@ -303,7 +331,7 @@ def main():
             msda = {"kernel": "msda_fused_level<2> (MSDA forward, encoder / late-fusion geometry, level in LDS, per-query offsets)",
                     "bound": "hbm", "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
-                    "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, per_rank)),
+                    "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, rank_frames)),
                     "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_msda_level_N8.md",
                     "launches_per_step": round(len(enc) / steps_profiled, 1), "bytes_per_launch": nbytes,
                     "avg_launch_us": round(mean_t * 1e6, 2),
@@ -319,12 +347,14 @@ def main():
             "metric": "frames/sec at 800x1333 RGB-D, TransVOD++ Late-Fusion", "value": round(fps, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(step_ms[len(step_ms) // 2], 3),
-            "higher_is_better": True, "scaling": "strong",
+            "higher_is_better": True, "scaling": "weak" if clips == world else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TransVOD++ LateFusion, {a.frames}-frame {a.height}x{a.width} RGB-D clip, "
                                    f"all-current mode (R={a.frames - 1}), L=1 DC5 (S={-(-a.height // 16) * -(-a.width // 16)}), 300 queries, 3 classes",
-                       "frames_per_gpu": per_rank, "micro_batch": min(a.micro_batch, per_rank),
-                       "parallelism": f"frame-shard x{world} + 1 all-gather/clip",
+                       "clips_per_step": clips, "frames_per_gpu": rank_frames, "frames_per_gpu_per_clip": per_rank,
+                       "micro_batch": min(a.micro_batch, rank_frames),
+                       "parallelism": f"every clip frame-sharded x{world} ({per_rank} frames/GPU), {clips} clip(s) per step, "
+                                      f"1 all-gather of the reference query sets per step",
                        "two_stream_overlap": overlapped, "clip_pipeline": pipelined},
             "roofline": roof,
             "roofline_kernels": kernels,
@@ -332,6 +362,11 @@ def main():
                     "fp32_mfma_frac": round(fps / world * FLOPS_PER_FRAME / FP32_MFMA_PEAK, 4),
                     "bytes_per_frame": BYTES_PER_FRAME, "flops_per_frame": FLOPS_PER_FRAME},
         }
+        if dt_single is not None:
+            line["single_clip_in_flight"] = {
+                "value": round(a.frames * a.steps / dt_single, 3), "unit": "frames/s", "ms_per_step": round(dt_single / a.steps * 1e3, 3),
+                "frames_per_gpu": per_rank, "scaling": "strong",
+                "note": "same run, after the timed region: one clip per step, every rank runs only its frames of it (latency mode)"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, min(a.cpu_threads, os.cpu_count() or 1))
         print(json.dumps(line), flush=True)

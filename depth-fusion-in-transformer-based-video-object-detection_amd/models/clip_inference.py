@@ -18,6 +18,12 @@ decoder) and its two query/RoI fusion passes run ONCE:
 
 Frames are independent until step 3 (frozen / eval-mode norms, per-sample attention), so the
 clip shards by contiguous blocks of frames with weights replicated.
+
+Several clips per call (``clips=B``): a rank that owns only T/world frames of a clip runs small kernels
+(4 frames per GPU at world = 8).  A stream of clips can be served B at a time instead: the rank's block is then
+its F frames of EACH of the B clips, [B*F, C, H, W] clip-major, steps 1+2 run on all B*F frames in one pass, step 3
+is still ONE all-gather (of all B clips' query sets), and step 4 lets every frame see the T-1 other frames of ITS OWN
+clip only.  Per clip the results are those of ``clips=1``.
 """
 import torch
 import torch.distributed as dist
@@ -159,31 +165,38 @@ class ClipRunner:
         return out
 
     # ---- step 3 ---------------------------------------------------------------------------------
-    def exchange(self, ref, logits):
+    def exchange(self, ref, logits, clips=1):
         """all-gather the per-frame reference query sets and logits over the clip's ranks.
-        ref [F,Q,C], logits [F,Q,K] -> ([T,Q,C], [T,Q,K]) in clip order (rank-major)."""
+        ref [B*F,Q,C], logits [B*F,Q,K] (clip-major: the rank's F frames of clip 0, of clip 1, ...) ->
+        ([B*T,Q,C], [B*T,Q,K]), clip-major with each clip's T = world * F frames in clip order (rank-major)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return ref, logits
         world = dist.get_world_size(self.group)
-        F_, Q, C = ref.shape
+        BF, Q, C = ref.shape
+        assert BF % clips == 0, "the rank's block must hold the same number of frames of every clip"
+        F_ = BF // clips
         K = logits.shape[-1]
         packed = torch.cat([ref, logits], dim=-1).contiguous()            # one message per rank
-        gathered = torch.empty((world * F_, Q, C + K), dtype=packed.dtype, device=packed.device)
+        gathered = torch.empty((world * BF, Q, C + K), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        if clips > 1:      # [world, B, F] -> [B, world, F]: every clip's frames together, in clip order
+            gathered = gathered.view(world, clips, F_, Q, C + K).transpose(0, 1).reshape(world * BF, Q, C + K)
         return gathered[..., :C].contiguous(), gathered[..., C:].contiguous()
 
     # ---- step 4 ---------------------------------------------------------------------------------
     @torch.no_grad()
-    def temporal_forward(self, local, all_ref, all_logits, first_frame):
-        """Outputs for each local frame t (global index first_frame + i) as the current frame, all
-        local frames in one batched pass."""
+    def temporal_forward(self, local, all_ref, all_logits, first_frame, clips=1):
+        """Outputs for each local frame as the current frame, all local frames in one batched pass.
+        local: the rank's B*F frames (clip-major); all_ref / all_logits [B*T,...] from ``exchange``; local frame i of
+        clip b is frame first_frame + i of that clip and sees the clip's other T-1 frames."""
         m, tr = self.model, self.model.transformer
-        T = all_ref.shape[0]
-        F_ = local["cur"].shape[0]
+        assert all_ref.shape[0] % clips == 0 and local["cur"].shape[0] % clips == 0
+        T = all_ref.shape[0] // clips
+        F_ = local["cur"].shape[0] // clips
         dev = all_ref.device
-        others = self._cached(("others", T, first_frame, F_, str(dev)), lambda: torch.as_tensor(
-            [[j for j in range(T) if j != first_frame + i] for i in range(F_)],
-            dtype=torch.long, device=dev))                                         # [F, T-1], clip order
+        others = self._cached(("others", T, first_frame, F_, clips, str(dev)), lambda: torch.as_tensor(
+            [[b * T + j for j in range(T) if j != first_frame + i] for b in range(clips) for i in range(F_)],
+            dtype=torch.long, device=dev))                                         # [B*F, T-1] rows of the pools, clip order
         final_hs, final_refs, _, picks = tr.temporal_stage(
             local["cur"], local["ref_last"], local["memory"], all_ref, all_logits, others,
             local["spatial_shapes"], local["level_start_index"], local["valid_ratios"],
@@ -193,17 +206,19 @@ class ClipRunner:
                 "topk_scores": tr.last_pick_scores}
 
     @torch.no_grad()
-    def __call__(self, frames, mask=None):
-        """frames: this rank's contiguous block of the clip, [T/world, C, H, W].
-        -> {"pred_logits" [F,Q,classes], "pred_boxes" [F,Q,4]} for the rank's frames."""
+    def __call__(self, frames, mask=None, clips=1):
+        """frames: this rank's contiguous block of the clip, [T/world, C, H, W] - or, with ``clips=B``, its block of
+        each of B clips, [B * T/world, C, H, W] clip-major.
+        -> {"pred_logits" [B*F,Q,classes], "pred_boxes" [B*F,Q,4]} for the rank's frames."""
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        assert frames.shape[0] % clips == 0, "the block must hold the same number of frames of every clip"
         local = self.frames_forward(frames, mask)
-        all_ref, all_logits = self.exchange(local["ref"], local["logits"])
-        return self.temporal_forward(local, all_ref, all_logits, first_frame=rank * frames.shape[0])
+        all_ref, all_logits = self.exchange(local["ref"], local["logits"], clips)
+        return self.temporal_forward(local, all_ref, all_logits, first_frame=rank * (frames.shape[0] // clips), clips=clips)
 
     # ---- a stream of clips ------------------------------------------------------------------------
     @torch.no_grad()
-    def submit(self, frames, mask=None):
+    def submit(self, frames, mask=None, clips=1):
         """Pipelined ``__call__`` for a stream of clips (serving): this clip's backbones are queued on one
         HIP stream, its transformer / query-RoI fusion / exchange / temporal stage on a second one, so
         the tail of clip k - many short kernels that leave most CUs idle - runs beside the backbones of
@@ -213,7 +228,7 @@ class ClipRunner:
         completed - ``done.synchronize()``, ``torch.cuda.current_stream().wait_event(done)`` or a device
         synchronize.  At most two clips are in flight; a third submit waits for the oldest."""
         if not frames.is_cuda:
-            out = self(frames, mask)
+            out = self(frames, mask, clips)
             return out, None
         dev = frames.device
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
@@ -235,8 +250,9 @@ class ClipRunner:
             with torch.cuda.stream(s_tail):
                 s_tail.wait_event(ready)
                 local = self._tail_block(staged)
-                all_ref, all_logits = self.exchange(local["ref"], local["logits"])
-                out = self.temporal_forward(local, all_ref, all_logits, first_frame=rank * frames.shape[0])
+                all_ref, all_logits = self.exchange(local["ref"], local["logits"], clips)
+                out = self.temporal_forward(local, all_ref, all_logits, first_frame=rank * (frames.shape[0] // clips),
+                                            clips=clips)
                 done = torch.cuda.Event()
                 done.record(s_tail)
         finally:

@@ -34,6 +34,33 @@ def rank_step(runner, x):
     return runner.temporal_forward(local, all_ref, all_logits, first_frame=0)
 
 
+def rank_step_weak(runner, x, B):
+    """throughput mode: the rank's F frames of each of B clips in one pass (x is [B * F, ...] clip-major)."""
+    local = runner.frames_forward(x)
+    F_ = x.shape[0] // B
+    rep = T // F_
+
+    def pool(t):        # stands in for the gathered queries: every clip's T frames = its own F frames repeated
+        return t.view(B, F_, *t.shape[1:]).repeat(1, rep, 1, 1).reshape(B * T, *t.shape[1:])
+    return runner.temporal_forward(local, pool(local["ref"]), pool(local["logits"]), first_frame=0, clips=B)
+
+
+if os.environ.get("WEAK", "1") == "1":
+    for world in (2, 4, 8):
+        F_ = T // world
+        x = torch.cat([clip[:F_]] * world, 0).to(dev)              # B = world clips
+        runner = ClipRunner(model, micro_batch=T, overlap=False)
+        for _ in range(2):
+            rank_step_weak(runner, x, world)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            rank_step_weak(runner, x, world)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 4
+        print(f"weak: N={world} GPUs, {world} clips per step, {F_} frames/GPU of each: {dt * 1e3:7.2f} ms/step "
+              f"-> {world * T / dt:7.1f} frames/s whole job (no exchange cost)", flush=True)
+
 CASES = os.environ.get('CASES')
 for F_, mb, ov in eval(CASES) if CASES else [(32, 8, False), (32, 8, True), (16, 8, False), (16, 8, True), (16, 4, True), (8, 8, False),
                    (8, 4, True), (8, 2, True), (4, 4, False), (4, 2, True), (4, 1, True)]:
