@@ -126,25 +126,27 @@ def test_clip_pipeline_submit_matches_call():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("clips_per_step", [0, 1])
-def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step):
+@pytest.mark.parametrize("clips_per_step,pipeline", [(0, 1), (1, 1), (0, 2)])
+def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline):
     """bench.py's own N > 1 code path (rank / world from the environment, frame sharding, barrier, MAX over ranks,
     rank 0 prints the line) with two ranks sharing this GPU over gloo - a rehearsal of the driver's RCCL launch on a
     small clip.  The line must parse and describe a 2-rank run: by default 2 clips per step (weak scaling, every rank
-    runs a clip's worth of frames) plus the one-clip-in-flight figure; --clips-per-step 1 is the strong-scaling mode."""
+    runs a clip's worth of frames) plus the one-clip-in-flight figure; --clips-per-step 1 is the strong-scaling mode;
+    --pipeline 2 puts the exchange on the side stream of the clip pipeline (ClipRunner.submit) with N > 1."""
     import json
     import subprocess
-    port = 29700 + (os.getpid() + 7 * clips_per_step) % 2000
+    port = 29700 + (os.getpid() + 7 * clips_per_step + 13 * pipeline) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4",
            "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--clips-per-step", str(clips_per_step)]
+           "--clips-per-step", str(clips_per_step), "--pipeline", str(pipeline)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["frames_per_gpu_per_clip"] == 2 and line["roofline"]["bound"] == "mfma"
+    assert line["config"]["clip_pipeline"] == (pipeline == 2)
     if clips_per_step == 0:
         assert line["scaling"] == "weak" and line["config"]["clips_per_step"] == 2 and line["config"]["frames_per_gpu"] == 4
         assert line["single_clip_in_flight"]["value"] > 0 and line["single_clip_in_flight"]["frames_per_gpu"] == 2
