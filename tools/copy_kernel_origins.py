@@ -1,7 +1,7 @@
 """Where do the small elementwise / copy kernels of a rank step come from?  torch.profiler with Python
 stacks, grouped by the innermost frame inside this repository.
 
-    python tools/copy_sources.py [frames=4]
+    python tools/copy_kernel_origins.py [frames=4]
 """
 import collections
 import os
