@@ -17,7 +17,10 @@ FRAMES=32 python3 $R/tools/bench_conv.py > $O/bench_conv_F32.txt 2>&1
 FRAMES=8 python3 $R/tools/bench_conv.py > $O/bench_conv_F8.txt 2>&1; echo "micro done"
 CASES="[(32,32,False),(16,16,False),(8,8,False),(4,4,False)]" python3 $R/tools/rank_step.py > $O/rank_step.txt 2>&1
 python3 $R/tools/stage_times.py 32 > $O/stage_times_mb32.txt 2>&1
-python3 $R/tools/conv_error.py > $O/conv_error.txt 2>&1; echo "all done"
+python3 $R/tools/conv_error.py > $O/conv_error.txt 2>&1
+python3 $R/tools/level_time.py 2.5 > $O/level_time.txt 2>&1
+python3 $R/tools/graph_step.py > $O/graph_step.txt 2>&1
+python3 $R/tools/launch_bound.py > $O/launch_bound.txt 2>&1; echo "all done"
 # the raw per-dispatch CSVs are large: keep the summaries
 rm -f $O/stats/*kernel_trace.csv $O/stats_p0/*kernel_trace.csv
 cat > $O/pmc_kernels_table.md <<'HDR'
