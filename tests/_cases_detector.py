@@ -9,6 +9,8 @@ state_dict name (tests/_param_fill.py), runs ``model(NestedTensor)`` and the pos
                                                                               deformable_detr_multi_plusplus.py:210-342)
   * ``PostProcess`` scores / labels / boxes and the implied box indices       (deformable_detr_single.py:569-603)
   * the inference filter ``softmax(-1)[0][:, 1] > keep_prob``                 (inference.py:918-930)
+  * the detector's ``state_dict`` keys and shapes (the checkpoint wire format; stub backbones
+    hold no parameters, so these are the transformer, ``input_proj*``, heads and query embeddings)
   * every ``torch.topk`` call the forward makes (values + int64 indices, in call order): the temporal stage's
     ordered picks of k*R reference queries                                    (deformable_transformer_multi_plusplus.py:529,554,576)
 
@@ -83,6 +85,12 @@ def run_detector_cases(ns, device="cpu"):
         for k, v in tensors.items():
             blobs[f"{case}.{k}"] = v.detach().cpu()
 
+    def put_state_dict(case, model):
+        # the checkpoint wire format: every state_dict key with its shape, as JSON bytes
+        import json
+        doc = json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}, sort_keys=True)
+        blobs[f"{case}.state_dict_json"] = torch.frombuffer(bytearray(doc.encode()), dtype=torch.uint8).clone()
+
     def post(case, det_mod, out, sizes):
         res = det_mod.PostProcess()(out, sizes)
         logits = out["pred_logits"]
@@ -113,6 +121,7 @@ def run_detector_cases(ns, device="cpu"):
                                    tr, num_classes=3, num_queries=Q, num_feature_levels=1, aux_loss=True,
                                    with_box_refine=True, two_stage=False, use_depth=True, depth_type=dtype_str).eval()
     fill_params_by_name(det, seed=41)
+    put_state_dict("det_single", det)
     det = det.to(device)
     x = _rnd(303, B, 4, H, W).to(device)
     with TopkRecorder():
@@ -134,6 +143,7 @@ def run_detector_cases(ns, device="cpu"):
                                     aux_loss=True, with_box_refine=True, two_stage=False, use_depth=True,
                                     depth_type=dtype_str).eval()
     fill_params_by_name(det, seed=51)
+    put_state_dict("det_multipp", det)
     det = det.to(device)
     x = _rnd(313, R + 1, 4, H, W).to(device)
     with TopkRecorder() as rec:

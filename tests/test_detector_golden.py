@@ -42,6 +42,16 @@ def check(got, golden):
     report = {}
     for key in sorted(got):
         ref, out = torch.from_numpy(golden[key]), got[key]
+        if key.endswith(".state_dict_json"):
+            # checkpoint wire format: the reference detector's state_dict keys and shapes, exactly
+            import json
+            want, have = json.loads(bytes(ref.tolist()).decode()), json.loads(bytes(out.tolist()).decode())
+            assert len(want) > 100
+            missing, extra = sorted(set(want) - set(have)), sorted(set(have) - set(want))
+            assert not missing and not extra, f"{key}: missing {missing[:5]} extra {extra[:5]}"
+            wrong = [k for k in want if want[k] != have[k]]
+            assert not wrong, f"{key}: shapes differ for {wrong[:5]}"
+            continue
         assert out.shape == ref.shape and out.dtype == ref.dtype, key
         if ref.is_floating_point():
             err = (out - ref).abs().max().item()
