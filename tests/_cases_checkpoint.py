@@ -1,0 +1,50 @@
+"""Shared recipe for the checkpoint-merge fixture: synthetic ``{'model': state_dict}`` files whose tensor
+VALUES name their origin (1 = the resumed checkpoint, 2 = the TransVOD temporal checkpoint, 3 = the spatial fine-tune),
+a zero-initialised target model whose key names hit every rule of the merge, and the cases to run.
+
+tools/gen_golden_inference.py runs the REFERENCE's own resume block (main_multi.py, ``if args.resume:`` ... the
+``total_ops`` filter, eval branch) on them; tests/test_inference_io.py runs models.inference_io.load_checkpoint."""
+import os
+
+import torch
+from torch import nn
+
+# (dataset_file, temporal checkpoint given, spatial checkpoint given)
+CASES = [("vid_multi_plusplus", True, True), ("vid_multi_plusplus", True, False), ("vid_multi", True, False),
+         ("vid_multi", True, True), ("vid_multi_plusplus", False, True), ("vid_multi_plusplus", False, False),
+         ("vid_single", True, False)]
+
+NAMES = ["backbone", "input_proj", "class_embed", "bbox_embed", "transformer_encoder", "temporal_query_layer1",
+         "temporal_decoder1", "temp_class_embed", "temp_bbox_embed", "dynamic_layer_for_current_query1", "only_in_model"]
+
+
+class Target(nn.Module):
+    def __init__(self):
+        super().__init__()
+        for n in NAMES:
+            setattr(self, n, nn.Linear(2, 2))
+        for p in self.parameters():
+            nn.init.zeros_(p)
+
+
+def write_checkpoints(folder):
+    keys = [k for k in Target().state_dict() if not k.startswith("only_in_model")]
+    full = lambda v: {k: torch.full((2, 2) if k.endswith("weight") else (2,), float(v)) for k in keys}  # noqa: E731
+    base = full(1)
+    base["stray_module.weight"] = torch.ones(1)                # unexpected for the model
+    base["backbone.total_ops"] = torch.zeros(1)                # thop counters: filtered from the report
+    temporal = full(2)
+    temporal["temporal_decoder1.total_params"] = torch.zeros(1)
+    temporal["dynamic_layer_for_current_query9.weight"] = torch.ones(1)
+    spatial = {k: v for k, v in full(3).items() if k.startswith(("backbone", "input_proj", "temp_bbox_embed"))}
+    paths = {}
+    for name, sd in (("base", base), ("temporal", temporal), ("spatial", spatial)):
+        paths[name] = os.path.join(folder, f"{name}.pth")
+        torch.save({"model": sd, "epoch": 7}, paths[name])
+    return paths
+
+
+def describe(model, missing, unexpected):
+    """-> JSON-able summary: origin of every tensor the model ended up with, and the reported key lists."""
+    return {"origin": {k: float(v.flatten()[0]) for k, v in model.state_dict().items()},
+            "missing": sorted(missing), "unexpected": sorted(unexpected)}

@@ -160,3 +160,26 @@ def test_reference_frame_sampling_and_clip_assembly_match_reference():
             rgb = [torch.full((3, 2, 2), float(i)) for i in ids]
             dep = [torch.full((1, 2, 2), -float(i)) for i in ids] if depth else None
             assert torch.equal(assemble_clip(rgb, dep)[:, 0, 0], want[row]), (key, img_id)
+
+
+def test_checkpoint_merge_matches_the_reference_resume_block(tmp_path):
+    """Row f3: the same synthetic checkpoints through models.inference_io.load_checkpoint and through the reference's own
+    resume block (main_multi.py:332-381, executed at fixture generation): every tensor of the model must come from the
+    same file (1 = resumed checkpoint, 2 = TransVOD temporal checkpoint, 3 = spatial fine-tune, 0 = left untouched) and
+    the missing / unexpected key reports must agree, for every dataset type and combination of companion files."""
+    import json
+
+    from tests._cases_checkpoint import CASES, Target, describe, write_checkpoints
+    want = json.loads(bytes(_golden()["checkpoint.merge_json"].tolist()).decode())
+    assert len(want) == len(CASES)
+    paths = write_checkpoints(str(tmp_path))
+    for (dataset_file, with_temporal, with_spatial), ref in zip(CASES, want):
+        target = Target()
+        missing, unexpected = io.load_checkpoint(target, paths["base"], paths["spatial"] if with_spatial else None,
+                                                 paths["temporal"] if with_temporal else None, dataset_file)
+        got = describe(target, missing, unexpected)
+        assert got == ref, (dataset_file, with_temporal, with_spatial,
+                            {k: (got["origin"][k], ref["origin"][k]) for k in ref["origin"] if got["origin"][k] != ref["origin"][k]},
+                            got["missing"], ref["missing"], got["unexpected"], ref["unexpected"])
+    # the fixture exercises every rule: temporal keys moved, dynamic_layer only for TransVOD++, spatial overlay wins
+    assert {v for c in want for v in c["origin"].values()} == {0.0, 1.0, 2.0, 3.0}

@@ -10,6 +10,10 @@ SURVEY.md 8c / tools/ref_import.py extended by import-only names).  What is call
   * ``DeformableDETR.get_image_and_reference_clips``                     inference.py:721-794  (reference-frame window,
     repetition, key-frame filter, [ (1+R)*C, H, W ] channel assembly) on a synthetic COCO-VID index whose "images"
     are constant tensors carrying their image id, so the output encodes which frames were sampled in which order.
+  * the checkpoint resume / merge block of main_multi.py (``if args.resume:`` ..., eval branch: temporal keys taken from
+    the TransVOD checkpoint per dataset type, spatial checkpoint laid over, ``strict=False`` load, thop counters
+    filtered from the report) - inline code of ``main()``, executed from the reference's file at generation time on
+    the synthetic checkpoints of tests/_cases_checkpoint.py.                                       main_multi.py:332-381
 """
 import os
 import sys
@@ -122,6 +126,32 @@ def sampled(num_ref, filter_key, depth):
 for num_ref, filter_key, depth in ((4, True, True), (2, False, False), (31, True, True), (1, True, False)):
     blobs[f"clips.R{num_ref}_filter{int(filter_key)}_depth{int(depth)}"] = sampled(num_ref, filter_key, depth).numpy()
 blobs["clips.video_of_image"] = np.asarray([[i, v] for v, ids in VIDEOS.items() for i in ids], dtype=np.int64)
+
+# ---- checkpoint merge (row f3): the reference's own resume block of main_multi.py, eval branch ---------------------------
+# The block is inline code of main() (not importable), so its source lines are read from the reference at generation time
+# and executed here on synthetic checkpoints (tests/_cases_checkpoint.py); nothing of it is stored in the repository.
+import json  # noqa: E402
+import tempfile  # noqa: E402
+import textwrap  # noqa: E402
+
+from tests._cases_checkpoint import CASES, Target, describe, write_checkpoints  # noqa: E402
+
+src = open(os.path.join(ref_import.REF, "main_multi.py")).read().splitlines()
+start = next(i for i, ln in enumerate(src) if ln.strip() == "if args.resume:")
+stop = next(i for i, ln in enumerate(src) if i > start and ln.strip().startswith("unexpected_keys = [k for k in unexpected_keys"))
+block = compile(textwrap.dedent("\n".join(src[start:stop + 1])), "main_multi.py resume block", "exec")
+results = []
+with tempfile.TemporaryDirectory() as tmp:
+    paths = write_checkpoints(tmp)
+    for dataset_file, with_temporal, with_spatial in CASES:
+        target = Target()
+        args = types.SimpleNamespace(resume=paths["base"], dataset_file=dataset_file, eval=True, coco_pretrain=False,
+                                     transvod_temporal_weights=paths["temporal"] if with_temporal else None,
+                                     spatial_weights=paths["spatial"] if with_spatial else None)
+        scope = {"torch": torch, "args": args, "model_without_ddp": target, "print": lambda *a, **k: None}
+        exec(block, scope)
+        results.append(describe(target, scope["missing_keys"], scope["unexpected_keys"]))
+blobs["checkpoint.merge_json"] = np.frombuffer(json.dumps(results, sort_keys=True).encode(), dtype=np.uint8)
 
 OUT = os.path.join(ROOT, "tests", "golden", "inference_io.npz")
 np.savez_compressed(OUT, **blobs)
