@@ -48,3 +48,32 @@ def describe(model, missing, unexpected):
     """-> JSON-able summary: origin of every tensor the model ended up with, and the reported key lists."""
     return {"origin": {k: float(v.flatten()[0]) for k, v in model.state_dict().items()},
             "missing": sorted(missing), "unexpected": sorted(unexpected)}
+
+
+# ---- DFormer partial load (dformer_backbone.py:161-198) ---------------------------------------------------------------
+def write_dformer_checkpoint(path, depth_backbone):
+    """A synthetic DFormer checkpoint ``{'state_dict': ...}``: for every conv / BatchNorm of the depth stem the tensors of
+    the depth branch (``backbone.downsample_layers_e.<i>.<j>.*``, values i*100 + j*10 + {1: weight, 2: bias, 3: running_mean,
+    4: running_var}), the same names of the RGB branch (``downsample_layers.``, must be ignored), one tensor of the wrong
+    shape and one unrelated key."""
+    sd = {}
+    for name, mod in depth_backbone.named_modules():
+        if not isinstance(mod, (nn.Conv2d, nn.BatchNorm2d)):
+            continue
+        _, i, j = name.split(".")
+        base = int(i) * 100 + int(j) * 10
+        for branch, offset in (("downsample_layers_e", 0.0), ("downsample_layers", 0.5)):
+            key = f"backbone.{branch}.{i}.{j}"
+            sd[key + ".weight"] = torch.full_like(mod.weight, base + 1 + offset)
+            sd[key + ".bias"] = torch.full_like(mod.bias, base + 2 + offset)
+            if isinstance(mod, nn.BatchNorm2d):
+                sd[key + ".running_mean"] = torch.full_like(mod.running_mean, base + 3 + offset)
+                sd[key + ".running_var"] = torch.full_like(mod.running_var, base + 4 + offset)
+                sd[key + ".num_batches_tracked"] = torch.tensor(7)
+    sd["backbone.downsample_layers_e.0.0.weight"] = torch.full((16, 1, 5, 5), 999.0)      # wrong shape: weight stays
+    sd["decode_head.conv_seg.weight"] = torch.ones(3)
+    torch.save({"state_dict": sd}, path)
+
+
+def describe_dformer(depth_backbone):
+    return {k: float(v.flatten()[0]) for k, v in depth_backbone.state_dict().items()}

@@ -183,3 +183,25 @@ def test_checkpoint_merge_matches_the_reference_resume_block(tmp_path):
                             got["missing"], ref["missing"], got["unexpected"], ref["unexpected"])
     # the fixture exercises every rule: temporal keys moved, dynamic_layer only for TransVOD++, spatial overlay wins
     assert {v for c in want for v in c["origin"].values()} == {0.0, 1.0, 2.0, 3.0}
+
+
+def test_dformer_partial_load_matches_the_reference(tmp_path):
+    """Row f3: DFormerBackbone.load_pretrained_weights on a synthetic DFormer checkpoint leaves every tensor of the depth
+    stem with the value the reference's method leaves it with (depth-branch keys only, running statistics untouched, the
+    shape rule for weights and the name rule for biases as they are in dformer_backbone.py:161-198)."""
+    import json
+    from types import SimpleNamespace
+
+    from models.dformer_backbone import build_dformer_backbone
+    from tests._cases_checkpoint import describe_dformer, write_dformer_checkpoint
+    want = json.loads(bytes(_golden()["checkpoint.dformer_json"].tolist()).decode())
+    back = build_dformer_backbone(SimpleNamespace(hidden_dim=256, position_embedding="sine", dformer_weights=None))[0]
+    with torch.no_grad():
+        for prm in back.depth_backbone.state_dict().values():
+            prm.zero_()
+    path = str(tmp_path / "dformer.pth")
+    write_dformer_checkpoint(path, back.depth_backbone)
+    back.load_pretrained_weights(back.depth_backbone, path)
+    got = describe_dformer(back.depth_backbone)
+    assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
+    assert any(v > 0 for v in want.values()) and any(v == 0 for k, v in want.items() if "running" in k)

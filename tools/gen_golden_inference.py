@@ -153,6 +153,20 @@ with tempfile.TemporaryDirectory() as tmp:
         results.append(describe(target, scope["missing_keys"], scope["unexpected_keys"]))
 blobs["checkpoint.merge_json"] = np.frombuffer(json.dumps(results, sort_keys=True).encode(), dtype=np.uint8)
 
+# ---- DFormer partial load (row f3): the reference's DFormerBackbone.load_pretrained_weights ------------------------------
+import models.dformer_backbone as ref_dfb  # noqa: E402
+
+from tests._cases_checkpoint import describe_dformer, write_dformer_checkpoint  # noqa: E402
+
+with tempfile.TemporaryDirectory() as tmp:
+    back = ref_dfb.build_dformer_backbone(types.SimpleNamespace(hidden_dim=256, position_embedding="sine", dformer_weights=None))[0]
+    for prm in back.depth_backbone.state_dict().values():
+        prm.zero_()
+    path = os.path.join(tmp, "dformer.pth")
+    write_dformer_checkpoint(path, back.depth_backbone)
+    back.load_pretrained_weights(back.depth_backbone, path)
+    blobs["checkpoint.dformer_json"] = np.frombuffer(json.dumps(describe_dformer(back.depth_backbone), sort_keys=True).encode(), dtype=np.uint8)
+
 OUT = os.path.join(ROOT, "tests", "golden", "inference_io.npz")
 np.savez_compressed(OUT, **blobs)
 print("wrote", OUT, {k: v.shape for k, v in blobs.items()})
