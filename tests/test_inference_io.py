@@ -205,3 +205,18 @@ def test_dformer_partial_load_matches_the_reference(tmp_path):
     got = describe_dformer(back.depth_backbone)
     assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
     assert any(v > 0 for v in want.values()) and any(v == 0 for k, v in want.items() if "running" in k)
+
+
+def test_label_files_match_the_reference_infer_tail():
+    """Row f1: the kept detections and the label lines (`Hand cx cy w h p`, 8 decimals) equal, character by character, what
+    the tail of the reference's infer() loop wrote for the same synthetic model outputs (inference.py:918-956, executed at
+    fixture generation); an image with no detection above keep_prob gets no label file there and no lines here."""
+    import json
+    cases = json.loads(bytes(_golden()["labels.cases_json"].tolist()).decode())
+    assert len(cases) == 4
+    for c in cases:
+        g = torch.Generator().manual_seed(c["seed"])
+        outputs = {"pred_logits": torch.randn(1, 40, 3, generator=g) * 2.0, "pred_boxes": torch.rand(1, 40, 4, generator=g)}
+        probs, boxes, idx = io.filter_detections(outputs, keep_prob=c["keep_prob"])
+        lines = io.yolo_lines(boxes, probs)
+        assert lines == (c["lines"] or []), (c["seed"], lines[:2], (c["lines"] or [])[:2])

@@ -10,6 +10,9 @@ SURVEY.md 8c / tools/ref_import.py extended by import-only names).  What is call
   * ``DeformableDETR.get_image_and_reference_clips``                     inference.py:721-794  (reference-frame window,
     repetition, key-frame filter, [ (1+R)*C, H, W ] channel assembly) on a synthetic COCO-VID index whose "images"
     are constant tensors carrying their image id, so the output encodes which frames were sampled in which order.
+  * the per-image tail of ``DeformableDETR.infer``: ``softmax(-1)[0][:, 1] > keep_prob`` filter and the label file
+    ``Hand cx cy w h p`` (8 decimals) it writes - inline code, executed from the reference's file on synthetic model
+    outputs.                                                                                      inference.py:918-956
   * the checkpoint resume / merge block of main_multi.py (``if args.resume:`` ..., eval branch: temporal keys taken from
     the TransVOD checkpoint per dataset type, spatial checkpoint laid over, ``strict=False`` load, thop counters
     filtered from the report) - inline code of ``main()``, executed from the reference's file at generation time on
@@ -152,6 +155,35 @@ with tempfile.TemporaryDirectory() as tmp:
         exec(block, scope)
         results.append(describe(target, scope["missing_keys"], scope["unexpected_keys"]))
 blobs["checkpoint.merge_json"] = np.frombuffer(json.dumps(results, sort_keys=True).encode(), dtype=np.uint8)
+
+# ---- post-filter + label file (row f1): the per-image tail of the reference's infer() loop --------------------------------
+# inline code of DeformableDETR.infer (inference.py, "probas = model_outputs['pred_logits']..." to the label f.write): read
+# from the reference at generation time and executed on synthetic model outputs; the label files it writes are the fixture.
+from pathlib import Path  # noqa: E402
+
+isrc = open(os.path.join(ref_import.REF, "inference.py")).read().splitlines()
+i0 = next(i for i, ln in enumerate(isrc) if ln.strip().startswith("probas = model_outputs['pred_logits'].softmax(-1)[0]"))
+i1 = next(i for i, ln in enumerate(isrc) if i > i0 and "f.write(f'Hand " in ln)
+tail = compile("for _once in (0,):\n" + textwrap.indent(textwrap.dedent("\n".join(isrc[i0:i1 + 1])), "    "),
+               "inference.py infer() tail", "exec")
+label_cases = []
+with tempfile.TemporaryDirectory() as tmp:
+    for case, (seed, keep_prob) in enumerate(((1, 0.5), (2, 0.3), (3, 0.999), (4, 0.7))):
+        g = torch.Generator().manual_seed(seed)
+        outputs = {"pred_logits": torch.randn(1, 40, 3, generator=g) * 2.0, "pred_boxes": torch.rand(1, 40, 4, generator=g)}
+        me = object.__new__(ref.DeformableDETR)
+        me.args = types.SimpleNamespace(keep_prob=keep_prob)
+        me.output_dir, me.img_path, me.save_txt, me.save_fig, me.depth_available = os.path.join(tmp, str(case)), tmp, True, False, False
+        me.plot_results = lambda *a, **k: None
+        scope = {"torch": torch, "os": os, "Path": Path, "tqdm": types.SimpleNamespace(write=lambda *a, **k: None), "self": me,
+                 "model_outputs": outputs, "original_img": types.SimpleNamespace(size=(640, 480)), "original_dpth": None,
+                 "img_file": os.path.join(tmp, "vid", f"frame{case}.jpg")}
+        exec(tail, scope)
+        label = os.path.join(me.output_dir, "labels", "vid", f"frame{case}.txt")
+        label_cases.append({"seed": seed, "keep_prob": keep_prob,
+                            "lines": open(label).read().splitlines() if os.path.exists(label) else None})
+assert any(c["lines"] is None for c in label_cases) and any(c["lines"] for c in label_cases)
+blobs["labels.cases_json"] = np.frombuffer(json.dumps(label_cases).encode(), dtype=np.uint8)
 
 # ---- DFormer partial load (row f3): the reference's DFormerBackbone.load_pretrained_weights ------------------------------
 import models.dformer_backbone as ref_dfb  # noqa: E402
