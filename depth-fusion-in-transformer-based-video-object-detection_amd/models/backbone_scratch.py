@@ -82,11 +82,12 @@ class FusionBackboneBase(nn.Module):
         assert m is not None, "Mask should not be None"
         body = self.body
         fused = self.fused_inference and not torch.is_grad_enabled()
-        x = body.stem(x, fused)
+        own = hasattr(body, "stem")      # models.resnet.ResNet50; any torchvision-style body works op by op (ref :112-131)
+        x = body.stem(x, fused) if own else body.maxpool(body.relu(body.bn1(body.conv1(x))))
         out: Dict[str, NestedTensor] = {}
         wanted = set(self.return_layers.values()) if self.return_interm_layers else set()
         for key, stage in (("0", body.layer1), ("1", body.layer2), ("2", body.layer3), ("3", body.layer4)):
-            x = body.run_stage(stage, x, fused)
+            x = body.run_stage(stage, x, fused) if own else stage(x)
             if key == "3":
                 # the last stage always reports; under key "3" only if such a key was requested
                 out["3" if key in wanted else "0"] = NestedTensor(x, _resize_mask(m, x.shape[-2:]))

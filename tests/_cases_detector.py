@@ -104,6 +104,41 @@ def run_detector_cases(ns, device="cpu"):
     dtype_str = "DepthDeform_latefusion_dformer"
     H, W = 160, 256                                        # stride-32 map: 5 x 8
 
+    # ---- RGB backbone wrapper (a14): FusionBackboneBase.forward + FrozenBatchNorm2d + Joiner around a small body -----
+    # (the real body is torchvision's ResNet-50, absent on both sides; what is pinned is everything the reference's own
+    # file does: RGB channel slice of the RGB-D input, stem / layer call order, FrozenBatchNorm2d arithmetic, the mask
+    # resized to every returned level, the returned-level dictionaries for one and for three levels, positions per level)
+    if hasattr(ns, "bsc"):
+        FBN = ns.bsc.FrozenBatchNorm2d
+
+        def block(ci, co, k, stride, dilation=1):
+            return nn.Sequential(nn.Conv2d(ci, co, k, stride, padding=dilation * (k // 2), dilation=dilation, bias=False), FBN(co), nn.ReLU())
+
+        class Body(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.conv1, self.bn1, self.relu = nn.Conv2d(3, 8, 7, 2, 3, bias=False), FBN(8), nn.ReLU()
+                self.maxpool = nn.MaxPool2d(3, 2, 1)
+                self.layer1, self.layer2 = block(8, 16, 1, 1), block(16, 24, 3, 2)
+                self.layer3, self.layer4 = block(24, 32, 3, 2), block(32, 40, 3, 1, dilation=2)
+
+        for interm in (False, True):
+            pe_b = PE(128, normalize=True)
+            base = ns.bsc.FusionBackboneBase("resnet50", "resnet18", Body(), None, pe_b, True, interm, dtype_str, [3], 256, False)
+            joiner = ns.bsc.Joiner(base, pe_b).eval()
+            fill_params_by_name(joiner, seed=71)
+            joiner = joiner.to(device)
+            xb = _rnd(72, 2, 4, 96, 128).to(device)
+            mb = torch.zeros(2, 96, 128, dtype=torch.bool)
+            mb[1, 70:, :] = True
+            mb[1, :, 100:] = True
+            feats, pos, _, _ = joiner(NestedTensor(xb, mb.to(device)))
+            case = f"backbone_wrapper_interm{int(interm)}"
+            put(case, n_levels=torch.tensor(len(feats)))
+            for i, (f, p_) in enumerate(zip(feats, pos)):
+                put(case, **{f"feat{i}": f.tensors, f"mask{i}": f.mask, f"pos{i}": p_})
+            put_state_dict(case, joiner)
+
     def masks(n):
         m = torch.zeros(n, H, W, dtype=torch.bool)
         if n > 1:

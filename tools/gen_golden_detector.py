@@ -20,6 +20,7 @@ import ref_import  # noqa: E402
 from oracle import msda_oracle  # noqa: E402
 
 ref_import.install(roi_align_fn=lambda x, rois, size, scale, ratio, aligned: msda_oracle.roi_align(x, rois, size, scale, ratio, aligned))
+import models.backbone_scratch as bsc  # noqa: E402
 import models.deformable_detr_multi_plusplus as multipp  # noqa: E402
 import models.deformable_detr_single as single  # noqa: E402
 import models.deformable_transformer_multi_plusplus as tpp  # noqa: E402
@@ -30,7 +31,7 @@ from util.misc_multi import NestedTensor as NestedTensorMulti  # noqa: E402
 
 from tests._cases_detector import run_detector_cases  # noqa: E402
 
-ns = SimpleNamespace(single=single, multipp=multipp, ts=ts, tpp=tpp, NestedTensor=NestedTensor, NestedTensorMulti=NestedTensorMulti,
+ns = SimpleNamespace(bsc=bsc, single=single, multipp=multipp, ts=ts, tpp=tpp, NestedTensor=NestedTensor, NestedTensorMulti=NestedTensorMulti,
                      PositionEmbeddingSine=PositionEmbeddingSine)
 torch.set_grad_enabled(False)
 blobs = {k: v.numpy() for k, v in run_detector_cases(ns).items()}
