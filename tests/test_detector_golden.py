@@ -54,8 +54,16 @@ def check(got, golden):
             assert not wrong, f"{key}: shapes differ for {wrong[:5]}"
             continue
         assert out.shape == ref.shape and out.dtype == ref.dtype, key
+        if ref.dtype == torch.bool and ".mask" in key:
+            assert torch.equal(out, ref), key
         if ref.is_floating_point():
-            err = (out - ref).abs().max().item()
+            diff = (out - ref).abs()
+            if ".pos" in key:
+                # sine positions of fully padded rows / columns are sin / cos of ~ -3e6 (0.5 / eps): ill-conditioned in
+                # fp32 and never read (masked); compared on the valid pixels
+                valid = ~torch.from_numpy(golden[key.replace(".pos", ".mask")])
+                diff = diff * valid[:, None].to(diff.dtype)
+            err = diff.max().item()
             scale = 1.0 if "pp_boxes" not in key else 640.0          # PostProcess boxes are in pixels
             assert err < 2e-4 * scale, f"{key}: max abs err {err:.3e}"
             report[key] = err
