@@ -53,6 +53,14 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
     return _pad_to_common(list(tensor_list))
 
 
+def collate_fn(batch):
+    """DataLoader collate of (image, target) samples: images padded into one NestedTensor, the rest transposed
+    (ref util/misc.py:304-307)."""
+    columns = list(zip(*batch))
+    columns[0] = nested_tensor_from_tensor_list(columns[0])
+    return tuple(columns)
+
+
 def inverse_sigmoid(x, eps=1e-5):
     x = x.clamp(min=0, max=1)
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))

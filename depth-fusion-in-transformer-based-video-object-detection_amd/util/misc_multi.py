@@ -14,3 +14,11 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor], split=True, channe
     for t in tensor_list:
         frames.extend(t.split(channel_size, dim=0) if split else [t])
     return _pad_to_common(frames)
+
+
+def collate_fn(batch, use_depth=False):
+    """DataLoader collate of (clip, target) samples; clips are cut into frames of 4 (RGB-D) or 3 channels
+    (ref util/misc_multi.py:304-308)."""
+    columns = list(zip(*batch))
+    columns[0] = nested_tensor_from_tensor_list(columns[0], split=True, channel_size=4 if use_depth else 3)
+    return tuple(columns)

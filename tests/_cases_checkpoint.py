@@ -77,3 +77,14 @@ def write_dformer_checkpoint(path, depth_backbone):
 
 def describe_dformer(depth_backbone):
     return {k: float(v.flatten()[0]) for k, v in depth_backbone.state_dict().items()}
+
+
+# ---- collate inputs (util/misc.py:304-356, util/misc_multi.py:304-345) -------------------------------------------------
+def collate_inputs():
+    """Ragged seeded images [3,H,W] and clips [(1+R)*C,H,W] (RGB-D: C = 4; RGB: C = 3; 'nosplit': plain 3-d tensors)."""
+    g = torch.Generator().manual_seed(77)
+    imgs = [torch.randn(3, h, w, generator=g) for h, w in ((11, 17), (13, 9), (8, 20))]
+    clips = {"rgbd": [torch.randn(3 * 4, h, w, generator=g) for h, w in ((10, 14), (12, 9))],
+             "rgb": [torch.randn(2 * 3, h, w, generator=g) for h, w in ((7, 7), (5, 12), (9, 3))],
+             "nosplit": [torch.randn(3, h, w, generator=g) for h, w in ((6, 8), (4, 10))]}
+    return imgs, clips

@@ -220,3 +220,24 @@ def test_label_files_match_the_reference_infer_tail():
         probs, boxes, idx = io.filter_detections(outputs, keep_prob=c["keep_prob"])
         lines = io.yolo_lines(boxes, probs)
         assert lines == (c["lines"] or []), (c["seed"], lines[:2], (c["lines"] or [])[:2])
+
+
+def test_collate_matches_the_reference():
+    """Row a17: ragged images / clips -> zero-padded batch + padding mask, bit for bit what the reference's util.misc and
+    util.misc_multi build (single-frame form; clip form with the channel split into frames for RGB-D and RGB; no split)."""
+    import util.misc as misc
+    import util.misc_multi as misc_multi
+    from tests._cases_checkpoint import collate_inputs
+    g = _golden()
+    imgs, clips = collate_inputs()
+    nt = misc.nested_tensor_from_tensor_list(imgs)
+    assert torch.equal(nt.tensors, torch.from_numpy(g["collate.single_tensors"])) and torch.equal(nt.mask, torch.from_numpy(g["collate.single_mask"]))
+    batch = misc.collate_fn([(im, {"i": i}) for i, im in enumerate(imgs)])
+    assert torch.equal(batch[0].tensors, torch.from_numpy(g["collate.single_collate_fn_tensors"])) and batch[1] == ({"i": 0}, {"i": 1}, {"i": 2})
+    for split, cs, tag in ((True, 4, "rgbd"), (True, 3, "rgb"), (False, 3, "nosplit")):
+        nt = misc_multi.nested_tensor_from_tensor_list(clips[tag], split=split, channel_size=cs)
+        assert torch.equal(nt.tensors, torch.from_numpy(g[f"collate.multi_{tag}_tensors"])), tag
+        assert torch.equal(nt.mask, torch.from_numpy(g[f"collate.multi_{tag}_mask"])), tag
+    batch = misc_multi.collate_fn([(c, {"i": i}) for i, c in enumerate(clips["rgbd"])], use_depth=True)
+    assert torch.equal(batch[0].tensors, torch.from_numpy(g["collate.multi_collate_fn_tensors"]))
+    assert torch.equal(batch[0].mask, torch.from_numpy(g["collate.multi_collate_fn_mask"]))

@@ -10,6 +10,9 @@ SURVEY.md 8c / tools/ref_import.py extended by import-only names).  What is call
   * ``DeformableDETR.get_image_and_reference_clips``                     inference.py:721-794  (reference-frame window,
     repetition, key-frame filter, [ (1+R)*C, H, W ] channel assembly) on a synthetic COCO-VID index whose "images"
     are constant tensors carrying their image id, so the output encodes which frames were sampled in which order.
+  * ``util.misc`` / ``util.misc_multi``: ``nested_tensor_from_tensor_list`` and ``collate_fn`` on ragged images and
+    clips (zero padding, padding masks, the channel split of a [(1+R)*C, H, W] clip into frames).   util/misc.py:304-356,
+                                                                                                    util/misc_multi.py:304-345
   * the per-image tail of ``DeformableDETR.infer``: ``softmax(-1)[0][:, 1] > keep_prob`` filter and the label file
     ``Hand cx cy w h p`` (8 decimals) it writes - inline code, executed from the reference's file on synthetic model
     outputs.                                                                                      inference.py:918-956
@@ -155,6 +158,23 @@ with tempfile.TemporaryDirectory() as tmp:
         exec(block, scope)
         results.append(describe(target, scope["missing_keys"], scope["unexpected_keys"]))
 blobs["checkpoint.merge_json"] = np.frombuffer(json.dumps(results, sort_keys=True).encode(), dtype=np.uint8)
+
+# ---- collate (row a17): ragged images -> padded batch + mask, single-frame and clip (channel-split) forms -----------------
+import util.misc as ref_misc  # noqa: E402
+import util.misc_multi as ref_misc_multi  # noqa: E402
+
+from tests._cases_checkpoint import collate_inputs  # noqa: E402
+
+imgs, clips = collate_inputs()
+nt = ref_misc.nested_tensor_from_tensor_list(imgs)
+blobs["collate.single_tensors"], blobs["collate.single_mask"] = nt.tensors.numpy(), nt.mask.numpy()
+batch = ref_misc.collate_fn([(im, {"i": i}) for i, im in enumerate(imgs)])
+blobs["collate.single_collate_fn_tensors"] = batch[0].tensors.numpy()
+for split, cs, tag in ((True, 4, "rgbd"), (True, 3, "rgb"), (False, 3, "nosplit")):
+    nt = ref_misc_multi.nested_tensor_from_tensor_list(clips[tag], split=split, channel_size=cs)
+    blobs[f"collate.multi_{tag}_tensors"], blobs[f"collate.multi_{tag}_mask"] = nt.tensors.numpy(), nt.mask.numpy()
+batch = ref_misc_multi.collate_fn([(c, {"i": i}) for i, c in enumerate(clips["rgbd"])], use_depth=True)
+blobs["collate.multi_collate_fn_tensors"], blobs["collate.multi_collate_fn_mask"] = batch[0].tensors.numpy(), batch[0].mask.numpy()
 
 # ---- post-filter + label file (row f1): the per-image tail of the reference's infer() loop --------------------------------
 # inline code of DeformableDETR.infer (inference.py, "probas = model_outputs['pred_logits']..." to the label f.write): read
