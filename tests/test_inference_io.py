@@ -241,3 +241,11 @@ def test_collate_matches_the_reference():
     batch = misc_multi.collate_fn([(c, {"i": i}) for i, c in enumerate(clips["rgbd"])], use_depth=True)
     assert torch.equal(batch[0].tensors, torch.from_numpy(g["collate.multi_collate_fn_tensors"]))
     assert torch.equal(batch[0].mask, torch.from_numpy(g["collate.multi_collate_fn_mask"]))
+
+
+def test_box_conversions_match_the_reference():
+    from util import box_ops
+    g = _golden()
+    bx = torch.from_numpy(g["boxops.cxcywh"])
+    assert torch.equal(box_ops.box_cxcywh_to_xyxy(bx), torch.from_numpy(g["boxops.to_xyxy"]))
+    assert torch.equal(box_ops.box_xyxy_to_cxcywh(box_ops.box_cxcywh_to_xyxy(bx)), torch.from_numpy(g["boxops.back_to_cxcywh"]))

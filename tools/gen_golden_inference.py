@@ -176,6 +176,14 @@ for split, cs, tag in ((True, 4, "rgbd"), (True, 3, "rgb"), (False, 3, "nosplit"
 batch = ref_misc_multi.collate_fn([(c, {"i": i}) for i, c in enumerate(clips["rgbd"])], use_depth=True)
 blobs["collate.multi_collate_fn_tensors"], blobs["collate.multi_collate_fn_mask"] = batch[0].tensors.numpy(), batch[0].mask.numpy()
 
+# ---- box conversions (row a17) ------------------------------------------------------------------------------------------
+import util.box_ops as ref_box  # noqa: E402
+
+bx = torch.rand(29, 4, generator=torch.Generator().manual_seed(9))
+blobs["boxops.cxcywh"] = bx.numpy()
+blobs["boxops.to_xyxy"] = ref_box.box_cxcywh_to_xyxy(bx).numpy()
+blobs["boxops.back_to_cxcywh"] = ref_box.box_xyxy_to_cxcywh(ref_box.box_cxcywh_to_xyxy(bx)).numpy()
+
 # ---- post-filter + label file (row f1): the per-image tail of the reference's infer() loop --------------------------------
 # inline code of DeformableDETR.infer (inference.py, "probas = model_outputs['pred_logits']..." to the label f.write): read
 # from the reference at generation time and executed on synthetic model outputs; the label files it writes are the fixture.
