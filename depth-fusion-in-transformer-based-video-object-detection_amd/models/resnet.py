@@ -110,6 +110,10 @@ class ResNet50(nn.Module):
         self.layer2 = self._stage(128, 4, 2, replace_stride_with_dilation[0], norm_layer)
         self.layer3 = self._stage(256, 6, 2, replace_stride_with_dilation[1], norm_layer)
         self.layer4 = self._stage(512, 3, 2, replace_stride_with_dilation[2], norm_layer)
+        # torchvision's resnet50 also owns the ImageNet classifier; the detectors never call it, but a reference checkpoint
+        # carries `backbone.0.body.fc.{weight,bias}` and a strict load (benchmark.py:58) needs somewhere to put them
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, 1000)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

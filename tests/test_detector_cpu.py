@@ -107,3 +107,30 @@ def test_transvod_builds_and_runs(cpu_msda):
     with torch.no_grad():
         out = model.eval()([_small_clip(3, seed=2, C=3).reshape(9, 64, 96)])
     assert out["pred_logits"].shape == (1, 300, 3)
+
+
+def test_resnet50_body_keeps_torchvisions_checkpoint_contract():
+    """torchvision is absent on both sides, so the ResNet-50 body cannot be pinned by a reference run; what is
+    checked is torchvision's published contract that reference checkpoints are written against: 25 557 032 parameters
+    (23 508 032 without the classifier), the block layout 3-4-6-3, the key names, FrozenBatchNorm2d buffers without
+    num_batches_tracked, and stride 16 with the last stage dilated (DC5)."""
+    import torch
+    from models.backbone_scratch import FrozenBatchNorm2d
+    from models.resnet import ResNet50
+    m = ResNet50(FrozenBatchNorm2d, replace_stride_with_dilation=[False, False, True])
+    sd = m.state_dict()
+    n_params = sum(p.numel() for p in m.parameters())
+    n_frozen = sum(b.weight.numel() + b.bias.numel() for b in m.modules() if isinstance(b, FrozenBatchNorm2d))   # affine terms live in buffers
+    assert n_params + n_frozen == 25_557_032, n_params + n_frozen
+    assert [len(getattr(m, f"layer{i}")) for i in (1, 2, 3, 4)] == [3, 4, 6, 3]
+    for key in ("conv1.weight", "bn1.running_var", "layer1.0.downsample.0.weight", "layer1.0.downsample.1.running_mean",
+                "layer3.5.conv3.weight", "layer4.2.bn3.bias", "fc.weight", "fc.bias"):
+        assert key in sd, key
+    assert not any(k.endswith("num_batches_tracked") for k in sd)
+    assert sd["layer4.0.conv2.weight"].shape == (512, 512, 3, 3) and m.layer4[0].conv2.stride == (1, 1)
+    assert m.layer4[1].conv2.dilation == (2, 2) and m.layer4[0].conv2.dilation == (1, 1)
+    with torch.no_grad():
+        x = m.stem(torch.zeros(1, 3, 64, 96))
+        for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
+            x = stage(x)
+    assert x.shape == (1, 2048, 4, 6)
