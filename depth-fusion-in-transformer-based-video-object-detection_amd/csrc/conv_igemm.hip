@@ -236,7 +236,8 @@ extern "C" int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *
     if ((long)N * Ho * Wo == 0) return DFX_OK;
     if (!x || !wp || !ktab || !y) return dfx::fail(DFX_EINVAL, "conv2d_igemm: null pointer");
     if (Kpad % 16 || !dfx::aligned16(wp)) return dfx::fail(DFX_EINVAL, "conv2d_igemm: Kpad must be a multiple of 16, wp 16-byte aligned");
-    if (KH * KW > 64) return dfx::fail(DFX_EINVAL, "conv2d_igemm: at most 64 taps");
+    if (KH * KW > 64 || KH > 32 || KW > 32)      // 64-bit tap mask built from 32-bit row and column validity masks
+        return dfx::fail(DFX_EINVAL, "conv2d_igemm: at most 64 taps, kernel sides up to 32");
     if (((long)Ci * H * W + (long)pad * W + pad) * 4 >= (1L << 31) || (long)Co * Ho * Wo >= (1L << 31) || (long)Co * Kpad * 4 >= (1L << 31))
         return dfx::fail(DFX_ERANGE, "conv2d_igemm: one image's tensor exceeds 2 GiB");
     if (N > 65535) return dfx::fail(DFX_ERANGE, "conv2d_igemm: batch too large");

@@ -47,7 +47,11 @@ struct Args {
     long cblk_stride;     // elements between column blocks (>= M * cblk)
     long ablk_stride;     // > 0: A is K-block-major, [K / 4][M][4] with this many elements between blocks
     int wide_epilogue;    // row-major C (and R) with 16-byte aligned rows, N % 4 == 0: float4 epilogue through LDS
-    int splits, kper;     // split-K: blockIdx.z = batch * splits + split, split s covers k in [s * kper, min(K, (s + 1) * kper))
+    int splits, kper;     // split-K: z = batch * splits + split, split s covers k in [s * kper, min(K, (s + 1) * kper))
+    int nx, ny;           // tiles along N and M (the grid is one-dimensional: nx * ny * nz workgroups)
+    int group_m;          // tile order (placement only, never results): 0 = n fastest, then m, then z, as dispatched;
+                          // > 0: workgroup ids are XCD-remapped (each XCD walks one contiguous range) and run m fastest inside
+                          // groups of group_m tile rows, then along the columns of every batch element
 };
 
 __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: exact (erf) GELU
@@ -78,8 +82,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    long bz = blockIdx.z;
+    // tile of this workgroup (scalar arithmetic; see Args::group_m)
+    int bx, by;
+    long bz;
+    {
+        int lin = blockIdx.x;
+        if (g.group_m > 0) {
+            lin = dfx::xcd_remap(lin, (int)gridDim.x);
+            const int nJ = (int)(gridDim.x / (unsigned)g.ny);           // columns of all batch elements
+            const int grp = lin / (g.group_m * nJ), y0 = grp * g.group_m;
+            const int gsz = min(g.ny - y0, g.group_m), r = lin - grp * g.group_m * nJ;
+            by = y0 + r % gsz;
+            const int J = r / gsz;
+            bx = J % g.nx;
+            bz = J / g.nx;
+        } else {
+            bx = lin % g.nx;
+            by = (lin / g.nx) % g.ny;
+            bz = lin / (g.nx * g.ny);
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const long cz = bz;                                   // C slice: one per (batch, split)
     int kbeg = 0, K = g.K;                                // this workgroup's K range
     if (g.splits > 1) {
@@ -402,10 +425,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 16>
-int launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
+// Tile order of a launch (Args::group_m): every XCD walks one contiguous range of tiles, 8 tile rows at a time with the
+// row fastest, so that the workgroups resident on an XCD share few operand panels in its 4 MiB L2.  Measured at 32 frames
+// (tools/bench_gemm.py, DFX_GEMM_GROUP = 0 / 1 / 2 / 4 / 8 / 16 / all rows in one process each, profiles/r03_gemm_order.txt):
+// 4 and 8 tie, 2.7 % less time over the path's shapes than the dispatch order (layer4 shortcut 4 %, layer2 conv3 6 %).
+int tile_group(const Args &g, int batch)
 {
-    const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch * (g.splits > 1 ? g.splits : 1)), block(256);
+    if (const char *e = getenv("DFX_GEMM_GROUP")) return atoi(e);
+    return 8;
+}
+
+template <int BM, int BN, int WM, int WN, int BK = 16>
+int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
+{
+    Args g = g_in;
+    g.nx = (g.N + BN - 1) / BN;
+    g.ny = (g.M + BM - 1) / BM;
+    const long total = (long)g.nx * g.ny * batch * (g.splits > 1 ? g.splits : 1);
+    if (total >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: too many tiles");
+    g.group_m = tile_group(g, batch);
+    const dim3 grid((unsigned)total), block(256);
     // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
     // or -2 (Linear), tag_b = tile
     const long flops = 2L * g.M * g.N * g.K * batch;
@@ -434,6 +473,7 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
                             long c_block_stride, long a_block_stride, void *stream)
 {
     if (M < 0 || N < 0 || K <= 0 || batch < 0) return dfx::fail(DFX_EINVAL, "gemm: bad dimension");
+    if (relu < 0 || relu > 2) return dfx::fail(DFX_EINVAL, "gemm: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
     if ((long)M * N * batch == 0) return DFX_OK;
     if (!A || !B || !C) return dfx::fail(DFX_EINVAL, "gemm: null pointer");
     if ((K & 3) || (lda & 3) || (ldb & 3) || (strideA & 3) || (strideB & 3) || !dfx::aligned16(A) || !dfx::aligned16(B) ||
@@ -534,6 +574,7 @@ extern "C" int dfx_gemm_splitk_f32(const float *A, long lda, const float *B, lon
                                    int act, int splits, float *workspace, void *stream)
 {
     if (M < 0 || N < 0 || K <= 0 || splits < 1) return dfx::fail(DFX_EINVAL, "gemm_splitk: bad dimension");
+    if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "gemm_splitk: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
     if ((long)M * N == 0) return DFX_OK;
     if (!A || !B || !C || !workspace) return dfx::fail(DFX_EINVAL, "gemm_splitk: null pointer");
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || !dfx::aligned16(A) || !dfx::aligned16(B) || !dfx::aligned16(workspace))

@@ -265,6 +265,9 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_GEMM_MAX_BYTES = 1 << 31          # tests lower it to exercise the row-range path on small tensors
+
+
 def _split_k(M, N, K):
     """Number of K ranges for a GEMM with few output tiles and a long K (0 = no split): as many as keep the
     128 x 128 (or 64 x 128 for small M) tiles x ranges within one resident round of workgroups (3 per CU for the
@@ -331,11 +334,23 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
                                          out.data_ptr(), N, M, N, K, code, splits, ws.data_ptr(), _stream(x.device))
             _lib.check(rc, "linear (split-K)")
             return out
-        rc = lib.dfx_gemm_f32(x2.data_ptr(), _ptr(add), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), 0,
-                              _ptr(residual), N, 0, _ptr(row_mask), 0, out.data_ptr(), N, 0, M, N, K, 1,
-                              code, int(col_block), M * int(col_block), M * 4 if x_blocked else 0,
-                              _stream(x.device))
-    _lib.check(rc, "linear")
+        # The kernel addresses an operand with 32-bit byte offsets (buffer loads): A, and the residual, must stay below
+        # 2 GiB per call.  More rows than that (long clips of multi-scale token maps) go through in row ranges; every
+        # layout here is row-separable (strides are explicit arguments), so a range is the same call on offset pointers.
+        rows_max = (_GEMM_MAX_BYTES - 1) // (4 * max(K, N if residual is not None else 1))
+        if x_blocked:
+            _require(M * K * 4 < _GEMM_MAX_BYTES, "linear: a K-block-major x of 2 GiB or more is not supported")
+            rows_max = M
+        rows_max = max(128, rows_max // 128 * 128)
+        out_row = int(col_block) if col_block else N            # elements a row advances the output pointer by
+        for r0 in range(0, M, rows_max):
+            r1 = min(M, r0 + rows_max)
+            off = lambda t, per_row: 0 if t is None else t.data_ptr() + r0 * per_row * t.element_size()  # noqa: E731
+            rc = lib.dfx_gemm_f32(off(x2, 4 if x_blocked else K), off(add, K), K, 0, weight.data_ptr(), K, 0, 0, _ptr(bias), 0,
+                                  off(residual, N), N, 0, off(row_mask, 1), 0, off(out, out_row), N, 0, r1 - r0, N, K, 1,
+                                  code, int(col_block), M * int(col_block), M * 4 if x_blocked else 0,
+                                  _stream(x.device))
+            _lib.check(rc, "linear")
     return out
 
 
@@ -465,12 +480,21 @@ class ConvPlan:
     convolutions with Ci % 8 == 0 and Co % 64 == 0 run as fused Winograd F(2x2, 3x3) (weights pre-transformed
     on the GPU by dfx_wino_weights_f32), everything else as an implicit GEMM over a tap table (weights
     re-ordered [Co, (ky, kx, ci)], K padded to a multiple of 16).  ``scale`` (per output channel, e.g. the
-    folded FrozenBatchNorm2d factor) is multiplied into the weights; ``bias`` and ``act`` run in the epilogue."""
+    folded FrozenBatchNorm2d factor) is multiplied into the weights; ``bias`` and ``act`` run in the epilogue.
+    ``weight`` is [Co, Ci, kh, kw] of an ungrouped convolution with zero padding: callers hand over ``conv.groups`` /
+    ``conv.padding_mode`` (or check them) - anything else raises."""
+    WINO_MAX_ELEMENTS = 1 << 30      # input elements per Winograd launch (32-bit offsets in the kernel); more go in image ranges
 
-    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, act=None, scale=None, algo=None):
+    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, act=None, scale=None, algo=None, groups=1,
+                 padding_mode="zeros"):
         _require(weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4, "ConvPlan: fp32 CUDA weight [Co,Ci,kh,kw]")
+        for nm, v in (("stride", stride), ("padding", padding), ("dilation", dilation)):
+            _require(not isinstance(v, (tuple, list)) or len(set(int(e) for e in v)) == 1,
+                     f"ConvPlan: {nm} must be the same along both axes (got {tuple(v) if isinstance(v, (tuple, list)) else v})")
         stride, padding, dilation = (v[0] if isinstance(v, (tuple, list)) else v for v in (stride, padding, dilation))
         Co, Ci, kh, kw = weight.shape
+        _require(groups == 1 and padding_mode == "zeros", "ConvPlan: grouped convolutions / non-zero padding modes are not covered")
+        _require(kh <= 32 and kw <= 32, "ConvPlan: kernel sides up to 32")
         self.Co, self.Ci, self.kh, self.kw = Co, Ci, kh, kw
         self.stride, self.padding, self.dilation, self.act = int(stride), int(padding), int(dilation), ACT[act]
         self.bias = None if bias is None else bias.detach().float().contiguous()
@@ -524,16 +548,22 @@ class ConvPlan:
             x = x.contiguous()
         Ho, Wo = self.out_size(H, W)
         y = torch.empty((N, self.Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        step = N
+        if self.algo == "wino" and N * self.Ci * H * W >= self.WINO_MAX_ELEMENTS:
+            step = max(1, (self.WINO_MAX_ELEMENTS - 1) // (self.Ci * H * W))
         with torch.cuda.device(x.device):
-            if self.algo == "wino":
-                rc = lib.dfx_conv3x3_wino_f32(x.data_ptr(), self.u.data_ptr(), _ptr(self.bias), y.data_ptr(), N, self.Ci,
-                                              H, W, self.Co, self.dilation, self.act, _stream(x.device))
-            else:
-                rc = lib.dfx_conv2d_igemm_f32(x.data_ptr(), self.wp.data_ptr(), self._ktab(H, W, x.device).data_ptr(),
-                                              _ptr(self.bias), y.data_ptr(), N, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad,
-                                              self.kh, self.kw, self.stride, self.padding, self.dilation, self.act,
-                                              image_stride, _stream(x.device))
-        _lib.check(rc, "conv " + self.algo)
+            for n0 in range(0, N, step):
+                n1 = min(N, n0 + step)
+                xs, ys = x[n0:n1], y[n0:n1]
+                if self.algo == "wino":
+                    rc = lib.dfx_conv3x3_wino_f32(xs.data_ptr(), self.u.data_ptr(), _ptr(self.bias), ys.data_ptr(), n1 - n0, self.Ci,
+                                                  H, W, self.Co, self.dilation, self.act, _stream(x.device))
+                else:
+                    rc = lib.dfx_conv2d_igemm_f32(xs.data_ptr(), self.wp.data_ptr(), self._ktab(H, W, x.device).data_ptr(),
+                                                  _ptr(self.bias), ys.data_ptr(), n1 - n0, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad,
+                                                  self.kh, self.kw, self.stride, self.padding, self.dilation, self.act,
+                                                  image_stride, _stream(x.device))
+                _lib.check(rc, "conv " + self.algo)
         return y
 
 

@@ -83,7 +83,7 @@ class ClipRunner:
         fs = tr.frame_stage(st["hs"][-1], st["inter_references"][-1], st["memory"], st["lvl_pos_embed_flatten"],
                             st["last_hw"], whwh, m.class_embed[-1], m.bbox_embed[-1], roles=("cur", "ref"))
         return {"cur": fs["cur"], "ref": fs["ref"], "logits": fs["logits"], "ref_last": st["inter_references"][-1],
-                "memory": st["memory"], "valid_ratios": st["valid_ratios"], "spatial_shapes": st["spatial_shapes"],
+                "hs_last": st["hs"][-1], "memory": st["memory"], "valid_ratios": st["valid_ratios"], "spatial_shapes": st["spatial_shapes"],
                 "level_start_index": st["level_start_index"]}
 
     @torch.no_grad()
@@ -97,7 +97,7 @@ class ClipRunner:
                                 lambda: torch.zeros((F_, H, W), dtype=torch.bool, device=frames.device))
         whwh = self._cached(("whwh", W, H, str(frames.device)), lambda: torch.as_tensor(
             (W, H, W, H), dtype=torch.long, device=frames.device).repeat(1, m.num_queries, 1))
-        keep = {k: [] for k in ("cur", "ref", "logits", "ref_last", "memory", "valid_ratios")}
+        keep = {k: [] for k in ("cur", "ref", "logits", "ref_last", "hs_last", "memory", "valid_ratios")}
         meta = []
 
         def encode(sl):
@@ -118,6 +118,7 @@ class ClipRunner:
             keep["ref"].append(fs["ref"])
             keep["logits"].append(fs["logits"])
             keep["ref_last"].append(st["inter_references"][-1])
+            keep["hs_last"].append(st["hs"][-1])
             keep["memory"].append(st["memory"])
             keep["valid_ratios"].append(st["valid_ratios"])
             meta.append((st["spatial_shapes"], st["level_start_index"]))
@@ -185,25 +186,27 @@ class ClipRunner:
 
     # ---- step 4 ---------------------------------------------------------------------------------
     @torch.no_grad()
-    def temporal_forward(self, local, all_ref, all_logits, first_frame, clips=1):
+    def temporal_forward(self, local, all_ref, all_logits, first_frame, clips=1, others=None):
         """Outputs for each local frame as the current frame, all local frames in one batched pass.
         local: the rank's B*F frames (clip-major); all_ref / all_logits [B*T,...] from ``exchange``; local frame i of
-        clip b is frame first_frame + i of that clip and sees the clip's other T-1 frames."""
+        clip b is frame first_frame + i of that clip and sees the clip's other T-1 frames - or, with ``others`` [F,R]
+        (long, rows of the pools), the reference frames the caller names, in that order (``VideoStream``)."""
         m, tr = self.model, self.model.transformer
         assert all_ref.shape[0] % clips == 0 and local["cur"].shape[0] % clips == 0
         T = all_ref.shape[0] // clips
         F_ = local["cur"].shape[0] // clips
         dev = all_ref.device
-        others = self._cached(("others", T, first_frame, F_, clips, str(dev)), lambda: torch.as_tensor(
-            [[b * T + j for j in range(T) if j != first_frame + i] for b in range(clips) for i in range(F_)],
-            dtype=torch.long, device=dev))                                         # [B*F, T-1] rows of the pools, clip order
+        if others is None:
+            others = self._cached(("others", T, first_frame, F_, clips, str(dev)), lambda: torch.as_tensor(
+                [[b * T + j for j in range(T) if j != first_frame + i] for b in range(clips) for i in range(F_)],
+                dtype=torch.long, device=dev))                                     # [B*F, T-1] rows of the pools, clip order
         final_hs, final_refs, _, picks = tr.temporal_stage(
             local["cur"], local["ref_last"], local["memory"], all_ref, all_logits, others,
             local["spatial_shapes"], local["level_start_index"], local["valid_ratios"],
             m.temp_class_embed_list, m.temp_bbox_embed_list)
         return {"pred_logits": m.temp_class_embed_list[2](final_hs),
                 "pred_boxes": apply_box_head(m.temp_bbox_embed_list[2], final_hs, final_refs), "topk": picks,
-                "topk_scores": tr.last_pick_scores}
+                "topk_scores": tr.last_pick_scores, "final_hs": final_hs}
 
     @torch.no_grad()
     def __call__(self, frames, mask=None, clips=1):
@@ -259,3 +262,88 @@ class ClipRunner:
             self.overlap = saved_overlap
         inflight.append((frames, staged, local, out, done))           # cross-stream tensors stay referenced until done
         return out, done
+
+
+class VideoStream:
+    """The reference's VIDEO inference mode as a stream (inference.py:750-765, 879-883): frame t of a video is detected
+    with the ``num_ref_frames`` frames ``sample_reference_ids(t, video, R)`` as its reference frames - the window
+    [t - R, t + R] without t, first R entries, i.e. the R PREVIOUS frames for every t >= R, and the first R + 1 frames of the
+    video without t for the frames before that (repeated when the video is shorter) - where ``ClipRunner.__call__`` serves a
+    fixed clip in which every frame sees all others.
+
+    Frames arrive in blocks (``push``); each frame's spatial stage and query/RoI fusion run once, its "ref" query set and
+    class logits go into a bank of the last R + 1 frames, and a frame's temporal stage runs as soon as its reference set is
+    complete: at once for t >= R, when frame R has arrived (or the video has ended) for the first R frames.  With several
+    ranks every ``push`` takes the rank's contiguous block of the world * F new frames (rank-major = frame order), the
+    per-frame sets are exchanged with the same single all-gather as a clip's, every rank keeps the whole bank and emits the
+    outputs of its own frames."""
+
+    def __init__(self, runner, num_ref_frames=None, filter_key_img=True):
+        self.runner = runner
+        self.R = int(num_ref_frames if num_ref_frames is not None else runner.model.transformer.num_ref_frames)
+        self.filter_key_img = filter_key_img
+        self.seen = 0              # frames of the video pushed so far (all ranks)
+        self.bank = {}             # frame index -> (ref [Q,C], logits [Q,K])
+        self.pending = {}          # frame index -> the frame's own tensors, until its output is emitted
+        self.meta = None
+
+    def _reference_ids(self, t, n):
+        from .inference_io import sample_reference_ids
+        return sample_reference_ids(t, list(range(n)), self.R, self.filter_key_img)
+
+    def _ready(self, t, ended):
+        """Reference set of frame t computable from the frames seen so far?  (the window reaches up to frame t + R, but
+        only its first R entries are used)"""
+        if ended:
+            return True
+        need = t if t >= self.R else self.R          # highest index among the first R entries of the window
+        if not self.filter_key_img:
+            need = t if t >= self.R else self.R - 1
+        return self.seen > max(need, t)
+
+    @torch.no_grad()
+    def push(self, frames, mask=None, last=False):
+        """frames [F,C,H,W]: this rank's block of the next world * F frames of the video; ``last``: the video ends with
+        this block.  -> [(frame index, {"pred_logits" [Q,K], "pred_boxes" [Q,4]}), ...] for the rank's frames whose
+        outputs became computable, in frame order."""
+        r = self.runner
+        world = dist.get_world_size(r.group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(r.group) if world > 1 else 0
+        F_ = frames.shape[0]
+        local = r.frames_forward(frames, mask)
+        all_ref, all_logits = r.exchange(local["ref"], local["logits"])
+        base = self.seen
+        for j in range(world * F_):
+            self.bank[base + j] = (all_ref[j], all_logits[j])
+        for i in range(F_):
+            self.pending[base + rank * F_ + i] = {k: local[k][i] for k in ("cur", "ref_last", "memory", "valid_ratios")}
+        self.meta = (local["spatial_shapes"], local["level_start_index"])
+        self.seen = base + world * F_
+        return self._emit(last)
+
+    def _emit(self, ended):
+        r = self.runner
+        m = r.model
+        ready = [t for t in sorted(self.pending) if self._ready(t, ended)]
+        out = []
+        if ready:
+            n = self.seen
+            ids = sorted(self.bank)
+            row = {t: i for i, t in enumerate(ids)}
+            refs = [self._reference_ids(t, n if ended else max(n, t + self.R + 1)) for t in ready]
+            dev = self.bank[ids[0]][0].device
+            others = torch.as_tensor([[row[j] for j in ref] for ref in refs], dtype=torch.long, device=dev)
+            pool_ref = torch.stack([self.bank[t][0] for t in ids])
+            pool_logits = torch.stack([self.bank[t][1] for t in ids])
+            local = {k: torch.stack([self.pending[t][k] for t in ready]) for k in ("cur", "ref_last", "memory", "valid_ratios")}
+            local["spatial_shapes"], local["level_start_index"] = self.meta
+            res = r.temporal_forward(local, pool_ref, pool_logits, 0, others=others)
+            for i, t in enumerate(ready):
+                out.append((t, {"pred_logits": res["pred_logits"][i], "pred_boxes": res["pred_boxes"][i]}))
+                del self.pending[t]
+        # frames no later frame can refer to: everything more than R behind the oldest frame still to be emitted / to come
+        # (the first R frames refer to frames 0 .. R: nothing goes while one of them is pending)
+        oldest = min(list(self.pending) + [self.seen])
+        for t in [t for t in self.bank if t < oldest - self.R]:
+            del self.bank[t]
+        return out

@@ -61,7 +61,8 @@ class _ConvGN(nn.Sequential):
         else:
             key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version)
             if getattr(self, "_plan", (None,))[0] != key:
-                self._plan = (key, _ops.ConvPlan(conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation))
+                self._plan = (key, _ops.ConvPlan(conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation,
+                                                 groups=conv.groups, padding_mode=conv.padding_mode))
             y = self._plan[1](x)
         return _ops.group_norm(y, norm, tokens_out=True)
 

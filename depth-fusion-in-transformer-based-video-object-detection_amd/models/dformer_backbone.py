@@ -117,7 +117,8 @@ class DFormerBackbone(nn.Module):
                 gelu = i < len(ops) and isinstance(ops[i], nn.GELU)
                 i += int(gelu)
                 # hand-written implicit-GEMM convolution, bias + GELU in its epilogue (csrc/conv_igemm.hip)
-                plan.append(_ops.ConvPlan(w, b, conv.stride, conv.padding, conv.dilation, "gelu" if gelu else None))
+                plan.append(_ops.ConvPlan(w, b, conv.stride, conv.padding, conv.dilation, "gelu" if gelu else None,
+                                          groups=conv.groups, padding_mode=conv.padding_mode))
             self._folded = (key, plan)
         for conv in self._folded[1]:
             x = conv(x)

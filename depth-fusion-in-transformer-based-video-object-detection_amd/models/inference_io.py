@@ -9,6 +9,10 @@ Before the path
   ``load_checkpoint``        the reference's checkpoint wire format {'model': state_dict, ...} incl. the
                              temporal / spatial weight merging of main_multi.py:333-394 and
                              inference.py:807-823
+The caller itself
+  ``FrameInference``         the body of the reference's ``infer()`` loop (inference.py:879-956) as one chain on the GPU:
+                             preprocessing kernel -> model (single frame) or ClipRunner (TransVOD++, every frame of the
+                             clip as current frame) -> post-filter -> box rescale -> label lines
 After the path
   ``filter_detections``      softmax over classes, keep queries whose class-1 ("hand") probability exceeds
                              ``keep_prob`` (inference.py:918-930)
@@ -99,3 +103,50 @@ def rescale_bboxes(out_bbox, size):
 def yolo_lines(normalized_boxes, probs, label="Hand"):
     return [f"{label} {cx:.8f} {cy:.8f} {w:.8f} {h:.8f} {p:.8f}"
             for (cx, cy, w, h), p in zip(normalized_boxes.tolist(), probs.tolist())]
+
+
+class FrameInference:
+    """The per-image body of the reference's inference loop (inference.py:879-956) chained on the GPU:
+
+        uint8 frames -> fused resize / normalise / pad kernel (models/preprocess.py, row f4)
+                     -> ``model(NestedTensor)`` for the single-frame detectors, or ``ClipRunner`` for TransVOD(++)
+                        clips (every frame of the clip is a current frame, models/clip_inference.py)
+                     -> ``softmax(-1)[:, 1] > keep_prob`` -> kept boxes, pixel boxes of the ORIGINAL image,
+                        label lines ``Hand cx cy w h p`` (row f1)
+
+    One result dict per frame: probs [K], boxes [K,4] (normalised cxcywh), queries [K] (indices of the kept queries),
+    boxes_px [K,4] (x1,y1,x2,y2 in the original image), lines (list of str; empty = the reference writes no file)."""
+
+    def __init__(self, model, keep_prob=0.5, size=600, max_size=1333, micro_batch=32):
+        from .clip_inference import ClipRunner
+        from .fused import enable_fused_inference
+        from .preprocess import ClipPreprocessor
+        self.model = model.eval()
+        self.keep_prob = keep_prob
+        dev = next(model.parameters()).device
+        self.pre = ClipPreprocessor(size, max_size, device=dev)
+        self.is_clip_model = hasattr(model.transformer, "temporal_stage")
+        if self.is_clip_model:
+            self.runner = ClipRunner(model, micro_batch=micro_batch)
+        else:
+            enable_fused_inference(model, dev.type == "cuda")
+
+    def _finish(self, outputs, b, size_wh):
+        probs, boxes, idx = filter_detections(outputs, self.keep_prob, b)
+        return {"probs": probs, "boxes": boxes, "queries": idx, "boxes_px": rescale_bboxes(boxes, size_wh),
+                "lines": yolo_lines(boxes, probs)}
+
+    @torch.no_grad()
+    def image(self, rgb_u8, depth_u8=None):
+        """One image through a single-frame detector (``dataset_file == 'vid_single'``, inference.py:884-889)."""
+        nt = self.pre([rgb_u8], None if depth_u8 is None else [depth_u8])
+        return self._finish(self.model(nt), 0, (rgb_u8.shape[1], rgb_u8.shape[0]))
+
+    @torch.no_grad()
+    def clip(self, rgb_frames, depth_frames=None):
+        """A clip of T frames through TransVOD(++): frame t's result is the reference's for the clip
+        [t, the other frames in clip order] (inference.py:879-883 with that clip)."""
+        nt = self.pre(rgb_frames, depth_frames)
+        padded = bool(nt.mask.any())
+        out = self.runner(nt.tensors, nt.mask if padded else None)
+        return [self._finish(out, t, (f.shape[1], f.shape[0])) for t, f in enumerate(rgb_frames)]

@@ -54,7 +54,7 @@ class Bottleneck(nn.Module):
             # conv2 on the hand-written kernels (Winograd F(2x2,3x3) for stride 1 incl. the dilated stage,
             # implicit GEMM for stride 2): folded-BN scale in the weights, shift + ReLU in the epilogue
             plan2 = _ops.ConvPlan(c2.weight, shift2.detach(), c2.stride, c2.padding, c2.dilation, "relu",
-                                  scale=scale2.detach())
+                                  scale=scale2.detach(), groups=c2.groups, padding_mode=c2.padding_mode)
             f = [_fold(self.conv1, self.bn1), plan2, _fold(self.conv3, self.bn3)]
             f.append(_fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None)
             self._folded = (key, f)
@@ -81,7 +81,9 @@ class Bottleneck(nn.Module):
             return _ops.conv1x1(x, w, b, residual=residual, relu=relu, stride=stride)
         # strided shortcut (the implicit GEMM gathers every other pixel itself: no subsampled copy of the map) and
         # maps whose rows are not 16-byte aligned
-        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        # keyed on the version key of the parameters the folded tensors were made from (the folded temporaries' own
+        # addresses / versions say nothing: the allocator hands an address out again after a refold)
+        key = self._folded[0]
         plans = self.__dict__.setdefault("_plans1x1", {})
         fused = residual is None
         if slot not in plans or plans[slot][0] != key:

@@ -91,7 +91,7 @@ def run_detector_cases(ns, device="cpu"):
         doc = json.dumps({k: list(v.shape) for k, v in model.state_dict().items()}, sort_keys=True)
         blobs[f"{case}.state_dict_json"] = torch.frombuffer(bytearray(doc.encode()), dtype=torch.uint8).clone()
 
-    def post(case, det_mod, out, sizes):
+    def post(case, det_mod, out, sizes, keep_prob=KEEP_PROB):
         res = det_mod.PostProcess()(out, sizes)
         logits = out["pred_logits"]
         # the indices PostProcess gathers the boxes with (it does not return them): same rule, same call
@@ -99,7 +99,7 @@ def run_detector_cases(ns, device="cpu"):
         put(case, pp_scores=torch.stack([r["scores"] for r in res]), pp_labels=torch.stack([r["labels"] for r in res]),
             pp_boxes=torch.stack([r["boxes"] for r in res]), pp_box_idx=idx // logits.shape[2])
         probas = logits.softmax(-1)[0]
-        put(case, keep_probas=probas[:, 1], keep_mask=probas[:, 1] > KEEP_PROB)
+        put(case, keep_probas=probas[:, 1], keep_mask=probas[:, 1] > keep_prob, keep_prob=torch.tensor(keep_prob))
 
     dtype_str = "DepthDeform_latefusion_dformer"
     H, W = 160, 256                                        # stride-32 map: 5 x 8
@@ -189,6 +189,31 @@ def run_detector_cases(ns, device="cpu"):
     for i, (vals, idx) in enumerate(rec.calls):
         put("det_multipp", **{f"topk{i}_values": vals, f"topk{i}_idx": idx})
     post("det_multipp", ns.multipp, out, torch.as_tensor([[480, 640]], device=device))
+
+    # ---- TransVOD++ RGB (``--fusion_type Baseline``, configs/training/TransVOD++.sh; BASELINE.json configs[3]): the
+    # 3-channel branch of the multi++ detector - no depth backbone, no input_proj_depth, no fusion layer (a16, a11) ----
+    R, Q = 3, 90
+    tr = ns.tpp.DeformableTransformer(d_model=256, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                      dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=True,
+                                      num_feature_levels=1, dec_n_points=4, enc_n_points=4, two_stage=False,
+                                      two_stage_num_proposals=Q, num_query=Q, n_temporal_decoder_layers=1,
+                                      num_ref_frames=R, fixed_pretrained_model=False, args=None, use_depth=False,
+                                      depth_type="Baseline_rgb", dpth_n_points=4)
+    det = ns.multipp.DeformableDETR(StubJoiner(pe, NTM, 2048, 321), None, tr, num_classes=3, num_queries=Q,
+                                    num_feature_levels=1, num_ref_frames=R, aux_loss=True, with_box_refine=True,
+                                    two_stage=False, use_depth=False, depth_type="Baseline_rgb").eval()
+    fill_params_by_name(det, seed=61)
+    put_state_dict("det_multipp_rgb", det)
+    det = det.to(device)
+    x = _rnd(323, R + 1, 3, H, W).to(device)
+    with TopkRecorder() as rec:
+        out = det(NTM(x, torch.zeros(R + 1, H, W, dtype=torch.bool, device=device)))
+    put("det_multipp_rgb", pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"],
+        aux0_logits=out["aux_outputs"][0]["pred_logits"], aux1_boxes=out["aux_outputs"][1]["pred_boxes"])
+    assert len(rec.calls) == 3, "the temporal stage makes three top-k picks"
+    for i, (vals, idx) in enumerate(rec.calls):
+        put("det_multipp_rgb", **{f"topk{i}_values": vals, f"topk{i}_idx": idx})
+    post("det_multipp_rgb", ns.multipp, out, torch.as_tensor([[360, 480]], device=device), keep_prob=0.5)
     return blobs
 
 

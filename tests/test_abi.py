@@ -63,3 +63,17 @@ def test_module_has_reference_surface():
                     for p in ("weight", "bias")}
     assert m.im2col_step == 64
     assert m.sampling_offsets.weight.shape == (64, 256) and m.attention_weights.weight.shape == (32, 256)
+
+
+def test_entry_points_reject_bad_arguments_before_any_launch():
+    """Argument validation returns an error code without touching the GPU (no compute call is made here):
+    activation codes outside 0..2, kernel sides beyond the 32-bit tap masks of the implicit GEMM."""
+    from dfx import _lib
+    lib = _lib.load()
+    one = 16       # any non-null, 16-byte aligned address: the checks below fail before it would be used
+    rc = lib.dfx_gemm_f32(one, 0, 4, 0, one, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, one, 4, 0, 4, 4, 4, 1, 3, 0, 0, 0, None)
+    assert rc != 0 and b"activation" in lib.dfx_last_error()
+    rc = lib.dfx_gemm_splitk_f32(one, 4, one, 4, 0, 0, 0, 0, 0, one, 4, 4, 4, 4, 7, 2, one, None)
+    assert rc != 0 and b"activation" in lib.dfx_last_error()
+    rc = lib.dfx_conv2d_igemm_f32(one, one, one, 0, one, 1, 4, 8, 40, 4, 8, 8, 144, 1, 33, 1, 0, 1, 0, 0, None)
+    assert rc != 0 and b"kernel sides" in lib.dfx_last_error()

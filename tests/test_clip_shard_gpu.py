@@ -126,20 +126,22 @@ def test_clip_pipeline_submit_matches_call():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("clips_per_step,pipeline", [(0, 1), (1, 1), (0, 2)])
+@pytest.mark.parametrize("clips_per_step,pipeline", [(None, 1), (0, 1), (1, 2)])
 def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline):
     """bench.py's own N > 1 code path (rank / world from the environment, frame sharding, barrier, MAX over ranks,
     rank 0 prints the line) with two ranks sharing this GPU over gloo - a rehearsal of the driver's RCCL launch on a
-    small clip.  The line must parse and describe a 2-rank run: by default 2 clips per step (weak scaling, every rank
-    runs a clip's worth of frames) plus the one-clip-in-flight figure; --clips-per-step 1 is the strong-scaling mode;
-    --pipeline 2 puts the exchange on the side stream of the clip pipeline (ClipRunner.submit) with N > 1."""
+    small clip.  The line must parse and describe a 2-rank run: by default ONE clip in flight sharded over the ranks
+    (BASELINE.json's configuration, strong scaling) plus the N-clips-per-step throughput figure as an extra key;
+    --clips-per-step 0 makes the throughput mode the measured one (weak scaling); --pipeline 2 puts the exchange on the
+    side stream of the clip pipeline (ClipRunner.submit) with N > 1."""
     import json
     import subprocess
-    port = 29700 + (os.getpid() + 7 * clips_per_step + 13 * pipeline) % 2000
+    port = 29700 + (os.getpid() + 7 * (clips_per_step or 3) + 13 * pipeline) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4",
-           "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-           "--clips-per-step", str(clips_per_step), "--pipeline", str(pipeline)]
+           "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pipeline", str(pipeline)]
+    if clips_per_step is not None:
+        cmd += ["--clips-per-step", str(clips_per_step)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -149,9 +151,11 @@ def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline):
     assert line["config"]["clip_pipeline"] == (pipeline == 2)
     if clips_per_step == 0:
         assert line["scaling"] == "weak" and line["config"]["clips_per_step"] == 2 and line["config"]["frames_per_gpu"] == 4
-        assert line["single_clip_in_flight"]["value"] > 0 and line["single_clip_in_flight"]["frames_per_gpu"] == 2
+        assert "clip_stream_throughput" not in line
     else:
-        assert line["scaling"] == "strong" and line["config"]["frames_per_gpu"] == 2 and "single_clip_in_flight" not in line
+        assert line["scaling"] == "strong" and line["config"]["clips_per_step"] == 1 and line["config"]["frames_per_gpu"] == 2
+        extra = line["clip_stream_throughput"]
+        assert extra["value"] > 0 and extra["frames_per_gpu"] == 4 and extra["scaling"] == "weak"
 
 
 def test_clips_per_call_match_clip_by_clip_on_the_hip_path():

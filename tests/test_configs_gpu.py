@@ -1,0 +1,166 @@
+"""BASELINE.json's configurations end to end on the HIP path against the same host code on CPU tensors with the
+oracle as the two operators - at the sizes the baseline names, through ``build_model`` (round 3):
+
+  config A  single-frame RGB Deformable-DETR on the reference's sample image (OID 0000b7e1500c94d7.jpg, committed as
+            a uint8 pixel fixture): preprocessing kernel -> model -> post-filter -> rescale -> label lines
+            (``FrameInference``: the reference's inference.py:879-956 chained on the GPU)
+  config B  Late Fusion RGB-D, one 800x1333 image
+  config C  Encoder Cross Fusion RGB-D, one 800x1333 image
+  config D  TransVOD++ RGB (``--fusion_type Baseline``), 8-frame 3-channel clip: every ordered temporal pick
+            (k*R = 560 / 350 / 210) and the PostProcess indices, on a small clip and at 800x1333
+
+Weights are filled by state_dict name (tests/_param_fill.py), which spreads the class scores: the index comparisons
+cover at least 80 % of the ranks outside the 2e-5 tie margin and report how many they compared.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests._cases_detector import compare_indices
+
+pytestmark = pytest.mark.gpu
+TIE_MARGIN = 2e-5
+
+
+def _cpu_ops():
+    import models.ops.functions.ms_deform_attn_func as f
+    from dfx import ops
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    saved = (f.MSDeformAttnFunction, ops.roi_align)
+    _patch_cpu_ops()
+    return f, ops, saved
+
+
+def _make(args_fn, device, seed=8, temporal=False):
+    from models import build_model
+    from tests._param_fill import fill_params_by_name
+    model, _, post = build_model(args_fn(device))
+    fill_params_by_name(model, seed=seed)
+    with torch.no_grad():
+        heads = list(model.bbox_embed) + (list(model.temp_bbox_embed_list) if temporal else [])
+        for h in heads:
+            h.layers[-1].weight.mul_(0.2)
+        if temporal:          # spread the class scores the temporal picks rank by: 2480 picks need room outside the tie margin
+            for h in model.class_embed:
+                h.weight.mul_(3.0)
+                h.bias.sub_(2.0)
+    return model.to(device).eval(), post
+
+
+def _check_postprocess(post, got, want, sizes, min_frac=0.8):
+    lg, bx = got["pred_logits"].cpu(), got["pred_boxes"].cpu()
+    assert (lg - want["pred_logits"]).abs().max() < 1e-3 and (bx - want["pred_boxes"]).abs().max() < 1e-3
+    C = lg.shape[-1]
+    res_g, res_c = post["bbox"]({"pred_logits": lg, "pred_boxes": bx}, sizes), post["bbox"](want, sizes)
+    scores = torch.stack([r["scores"] for r in res_c])
+    idx_c = torch.topk(want["pred_logits"].sigmoid().flatten(1), 100, dim=1)[1]
+    idx_g = torch.topk(lg.sigmoid().flatten(1), 100, dim=1)[1]
+    n, bad = compare_indices(idx_c // C, idx_g // C, scores, TIE_MARGIN)
+    assert n >= min_frac * scores.numel() and bad == 0, f"PostProcess box indices: {bad} of {n} clear ranks differ"
+    n2, bad2 = compare_indices(torch.stack([r["labels"] for r in res_c]), torch.stack([r["labels"] for r in res_g]), scores, TIE_MARGIN)
+    assert n2 == n and bad2 == 0
+    return n / scores.numel()
+
+
+@pytest.mark.parametrize("fusion", ["LateFusion", "Encoder_CrossFusion"])
+@pytest.mark.timeout(900)
+def test_configs_b_c_one_800x1333_rgbd_image(fusion):
+    from models.config import single_args
+    from models.fused import enable_fused_inference
+    from util.misc import nested_tensor_from_tensor_list
+    img = torch.randn(4, 800, 1333, generator=torch.Generator().manual_seed(31))
+    gm, post = _make(lambda d: single_args(fusion, device=d), "cuda")
+    enable_fused_inference(gm)
+    with torch.no_grad():
+        got = gm(nested_tensor_from_tensor_list([img.cuda()]))
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = _make(lambda d: single_args(fusion, device=d), "cpu")
+        with torch.no_grad():
+            want = cm(nested_tensor_from_tensor_list([img]))
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    assert got["pred_logits"].shape == (1, 300, 3)
+    frac = _check_postprocess(post, got, want, torch.tensor([[800, 1333]]))
+    print(f"{fusion}: {frac:.0%} of the PostProcess ranks compared index by index")
+
+
+def _config_d(H, W, seed):
+    """TransVOD++ RGB through build_model / ClipRunner, 8 frames, every frame current with the 7 others as references."""
+    from models.clip_inference import ClipRunner
+    from models.config import transvodpp_args
+    args_fn = lambda d: transvodpp_args("Baseline", num_ref_frames=7, device=d)      # noqa: E731  configs/training/TransVOD++.sh
+    clip = torch.randn(8, 3, H, W, generator=torch.Generator().manual_seed(seed))
+    gm, post = _make(args_fn, "cuda", seed=5, temporal=True)
+    assert not hasattr(gm, "input_proj_depth") and gm.depth_backbone is None
+    got = ClipRunner(gm, micro_batch=8)(clip.cuda())
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = _make(args_fn, "cpu", seed=5, temporal=True)
+        want = ClipRunner(cm, micro_batch=4)(clip)
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    frac = _check_postprocess(post, got, want, torch.tensor([[H, W]] * 8))
+    fracs = []
+    assert [p.shape for p in want["topk"]] == [(8, 560), (8, 350), (8, 210)]          # k * R, k = 80 / 50 / 30, R = 7
+    for pg, pc, vc in zip(got["topk"], want["topk"], want["topk_scores"]):
+        n, bad = compare_indices(pc, pg.cpu(), vc, TIE_MARGIN)
+        assert n >= 0.8 * pc.numel() and bad == 0, f"ordered temporal pick: {bad} of {n} clear ranks differ"
+        fracs.append(n / pc.numel())
+    print(f"config D {H}x{W}: PostProcess ranks compared {frac:.0%}, temporal picks {[f'{x:.0%}' for x in fracs]}")
+
+
+def test_config_d_transvodpp_rgb_8_frame_clip_small():
+    _config_d(192, 288, 41)
+
+
+@pytest.mark.timeout(1200)
+def test_config_d_transvodpp_rgb_8_frame_clip_800x1333():
+    _config_d(800, 1333, 42)
+
+
+@pytest.mark.timeout(900)
+def test_config_a_sample_image_through_the_whole_caller(golden_dir):
+    """The reference's sample image, pixels from the committed fixture: preprocess kernel -> single-frame RGB detector ->
+    filter -> rescale -> label lines on the GPU, against the CPU chain (numpy restatement of Pillow's resampler pinned
+    in tests/test_preprocess.py -> CPU model with the oracle operator -> the same caller steps)."""
+    from models.config import single_args
+    from models.inference_io import FrameInference, filter_detections, rescale_bboxes, yolo_lines
+    from models.preprocess import RGB_MEAN, RGB_STD
+    from oracle import preprocess_oracle as po
+    from util.misc import NestedTensor
+    px = np.load(os.path.join(golden_dir, "oid_sample.npz"))["rgb"]
+    assert px.shape == (1024, 773, 3)
+    keep_prob = 0.5
+    gm, post = _make(lambda d: single_args("Baseline", device=d), "cuda")
+    got = FrameInference(gm, keep_prob=keep_prob).image(torch.from_numpy(px).cuda())
+    # CPU chain
+    x = torch.from_numpy(po.preprocess(px, RGB_MEAN, RGB_STD, 600, 1333))[None]
+    assert x.shape == (1, 3, 794, 600)
+    f, ops, saved = _cpu_ops()
+    try:
+        cm, _ = _make(lambda d: single_args("Baseline", device=d), "cpu")
+        with torch.no_grad():
+            want = cm(NestedTensor(x, torch.zeros(1, 794, 600, dtype=torch.bool)))
+    finally:
+        f.MSDeformAttnFunction, ops.roi_align = saved
+    probs, boxes, idx = filter_detections(want, keep_prob)
+    p_all = want["pred_logits"].softmax(-1)[0, :, 1]
+    clear = (p_all - keep_prob).abs() > TIE_MARGIN
+    kept_g = torch.zeros(300, dtype=torch.bool)
+    kept_g[got["queries"].cpu()] = True
+    kept_c = torch.zeros(300, dtype=torch.bool)
+    kept_c[idx] = True
+    assert torch.equal(kept_g[clear], kept_c[clear]) and 0 < int(kept_c.sum()) < 300
+    if torch.equal(kept_g, kept_c):
+        assert (got["probs"].cpu() - probs).abs().max() < 1e-4 and (got["boxes"].cpu() - boxes).abs().max() < 1e-4
+        assert (got["boxes_px"].cpu() - rescale_bboxes(boxes, (773, 1024))).abs().max() < 0.2
+        want_lines = yolo_lines(boxes, probs)
+        assert len(got["lines"]) == len(want_lines)
+        for a, b in zip(got["lines"], want_lines):                                # 'Hand cx cy w h p', 8 decimals
+            ta, tb = a.split(), b.split()
+            assert ta[0] == tb[0] == "Hand" and len(ta) == 6
+            assert max(abs(float(u) - float(v)) for u, v in zip(ta[1:], tb[1:])) < 1e-4
+    print(f"config A: {int(kept_c.sum())} detections kept, {int(clear.sum())} of 300 queries outside the tie margin of the threshold")

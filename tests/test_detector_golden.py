@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._cases_detector import KEEP_PROB, compare_indices, run_detector_cases
+from tests._cases_detector import compare_indices, run_detector_cases
 
 TIE_MARGIN = 2e-5
 
@@ -68,26 +68,29 @@ def check(got, golden):
             assert err < 2e-4 * scale, f"{key}: max abs err {err:.3e}"
             report[key] = err
     # int64: ordered index tensors, compared outside the tie margin
-    for case in ("det_single", "det_multipp"):
+    for case in ("det_single", "det_multipp", "det_multipp_rgb"):
         scores = torch.from_numpy(golden[f"{case}.pp_scores"])
         for name in ("pp_labels", "pp_box_idx"):
             n, bad = compare_indices(torch.from_numpy(golden[f"{case}.{name}"]), got[f"{case}.{name}"], scores, TIE_MARGIN)
-            assert n > 50 and bad == 0, f"{case}.{name}: {bad} of {n} clear ranks differ"
+            # the name-keyed weights spread the scores: at least 80 % of the ranks are compared index by index
+            assert n >= 0.8 * scores.numel() and bad == 0, f"{case}.{name}: {bad} of {n} clear ranks differ"
+            report[f"{case}.{name}.ranks_compared"] = n / scores.numel()
         p = torch.from_numpy(golden[f"{case}.keep_probas"])
-        clear = (p - KEEP_PROB).abs() > TIE_MARGIN
+        clear = (p - float(golden[f"{case}.keep_prob"])).abs() > TIE_MARGIN
         assert torch.equal(got[f"{case}.keep_mask"][clear], torch.from_numpy(golden[f"{case}.keep_mask"])[clear])
         assert 0 < int(golden[f"{case}.keep_mask"].sum()) < p.numel(), "the fixture's keep mask must be non-trivial"
-    for i in range(3):
-        ref_idx, vals = torch.from_numpy(golden[f"det_multipp.topk{i}_idx"]), torch.from_numpy(golden[f"det_multipp.topk{i}_values"])
-        n, bad = compare_indices(ref_idx, got[f"det_multipp.topk{i}_idx"], vals, TIE_MARGIN)
-        assert n > ref_idx.numel() // 2 and bad == 0, f"temporal top-k {i}: {bad} of {n} clear ranks differ"
+    for case, i in ((c, i) for c in ("det_multipp", "det_multipp_rgb") for i in range(3)):
+        ref_idx, vals = torch.from_numpy(golden[f"{case}.topk{i}_idx"]), torch.from_numpy(golden[f"{case}.topk{i}_values"])
+        n, bad = compare_indices(ref_idx, got[f"{case}.topk{i}_idx"], vals, TIE_MARGIN)
+        assert n >= 0.8 * ref_idx.numel() and bad == 0, f"{case} temporal top-k {i}: {bad} of {n} clear ranks differ"
+        report[f"{case}.topk{i}.ranks_compared"] = n / ref_idx.numel()
         # as a set the pick may only differ in candidates within the margin of the cut
         cut = vals[0, -1].item()
-        a, b = set(ref_idx[0].tolist()), set(got[f"det_multipp.topk{i}_idx"][0].tolist())
-        gvals = dict(zip(got[f"det_multipp.topk{i}_idx"][0].tolist(), got[f"det_multipp.topk{i}_values"][0].tolist()))
+        a, b = set(ref_idx[0].tolist()), set(got[f"{case}.topk{i}_idx"][0].tolist())
+        gvals = dict(zip(got[f"{case}.topk{i}_idx"][0].tolist(), got[f"{case}.topk{i}_values"][0].tolist()))
         rvals = dict(zip(ref_idx[0].tolist(), vals[0].tolist()))
         for j in a ^ b:
-            assert abs((rvals.get(j) if j in rvals else gvals[j]) - cut) <= TIE_MARGIN, f"top-k {i}: index {j} is not a tie at the cut"
+            assert abs((rvals.get(j) if j in rvals else gvals[j]) - cut) <= TIE_MARGIN, f"{case} top-k {i}: index {j} is not a tie at the cut"
     return report
 
 

@@ -291,3 +291,59 @@ def test_conv1x1_fuzz_shapes_match_fp64():
         want = (torch.nn.functional.conv2d(x.double(), w.double(), b.double()) + r.double()).relu()
         got = ops.conv1x1(x, w, b, residual=r, relu=True)
         assert (got.double() - want).abs().max().item() < 6e-6 * Ci ** 0.5, (trial, Nb, Ci, Co, H, W)
+
+
+def test_linear_runs_in_row_ranges_when_an_operand_would_pass_2_gib(monkeypatch):
+    """The kernel addresses A / the residual with 32-bit byte offsets; ops.linear hands more rows than that over in
+    row ranges (every layout is row-separable).  The limit is lowered here so that small tensors take the path:
+    identical bits to the one-call result, for the plain, the residual / add / mask and the column-block-major forms."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1000, 96, 256
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / 16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    add = torch.randn(M, K, generator=g).cuda()
+    mask = (torch.rand(M, generator=g) > 0.7).cuda()
+    whole = (ops.linear(x, w, b), ops.linear(x, w, b, relu=True, residual=res, add=add, row_mask=mask),
+             ops.linear(x, w, b, row_mask=mask, col_block=12))
+    monkeypatch.setattr(ops, "_GEMM_MAX_BYTES", 300 * K * 4)          # -> ranges of 256 rows
+    parts = (ops.linear(x, w, b), ops.linear(x, w, b, relu=True, residual=res, add=add, row_mask=mask),
+             ops.linear(x, w, b, row_mask=mask, col_block=12))
+    for a, c in zip(whole, parts):
+        assert torch.equal(a, c)
+
+
+@pytest.mark.timeout(600)
+def test_linear_just_above_the_2_gib_operand_limit():
+    """K = 1024 (the encoder FFN's second Linear) with 2^19 + 130 rows: A is 2 GiB + 520 KiB.  Checked on sampled rows
+    against float64, including rows of the second range."""
+    from dfx import ops
+    M, N, K = (1 << 19) + 130, 256, 1024
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / 32
+    b = torch.randn(N, device="cuda")
+    assert x.numel() * 4 >= 1 << 31
+    y = ops.linear(x, w, b, relu=True)
+    rows = torch.tensor([0, 1, 4095, (1 << 19) - 129, (1 << 19) - 1, 1 << 19, (1 << 19) + 129, M - 1], device="cuda")
+    want = (x[rows].double() @ w.double().t() + b.double()).relu()
+    assert (y[rows].double() - want).abs().max().item() < 4e-6 * K ** 0.5
+
+
+def test_conv_plan_runs_in_image_ranges_and_rejects_what_it_does_not_cover(monkeypatch):
+    """The Winograd kernel indexes its input with 32-bit element offsets (2^30 elements per launch): ConvPlan splits
+    larger batches into image ranges (limit lowered here: same bits as one launch).  Asymmetric strides / paddings,
+    grouped convolutions and non-zero padding modes raise instead of computing something else."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 16, 20, 28, generator=g).cuda()
+    wt = (torch.randn(64, 16, 3, 3, generator=g) / 12).cuda()
+    plan = ops.ConvPlan(wt, torch.randn(64, generator=g).cuda(), 1, 1, 1, "relu")
+    assert plan.algo == "wino"
+    whole = plan(x)
+    monkeypatch.setattr(ops.ConvPlan, "WINO_MAX_ELEMENTS", 2 * 16 * 20 * 28 + 1)     # -> 2 images per launch
+    assert torch.equal(plan(x), whole)
+    for bad in (dict(stride=(1, 2)), dict(padding=(1, 0)), dict(dilation=(2, 1)), dict(groups=2), dict(padding_mode="reflect")):
+        with pytest.raises(RuntimeError):
+            ops.ConvPlan(wt, None, **bad)

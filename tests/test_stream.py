@@ -1,0 +1,123 @@
+"""The reference's VIDEO inference mode served as a stream (models.clip_inference.VideoStream) against outputs of the
+REFERENCE's own caller + detector on the same synthetic videos (tests/golden/stream.npz, tools/gen_golden_stream.py,
+recipe tests/_cases_stream.py): per frame, the clip ``get_image_and_reference_clips`` assembles (window [t-R, t+R]
+without t, first R ids, repeated when the video is short) through the reference's TransVOD++ forward.
+
+CPU: the oracle as the MSDA / RoIAlign operator, frames pushed in uneven blocks; the same with two ranks over gloo (frames
+of each block sharded, one all-gather per block)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests._cases_stream import VIDEOS, build_detector, video_frames
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd")
+
+
+def my_namespace():
+    import models.deformable_detr_multi_plusplus as multipp
+    import models.deformable_transformer_multi_plusplus as tpp
+    from models.position_encoding import PositionEmbeddingSine
+    from util.misc_multi import NestedTensor as NestedTensorMulti
+    return SimpleNamespace(multipp=multipp, tpp=tpp, NestedTensorMulti=NestedTensorMulti, PositionEmbeddingSine=PositionEmbeddingSine)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "stream.npz"))
+
+
+def _compare(name, results, golden, tol=2e-4):
+    n = VIDEOS[name]["n"]
+    assert sorted(t for t, _ in results) == list(range(n)), f"{name}: every frame gets exactly one output"
+    for t, out in results:
+        for key in ("pred_logits", "pred_boxes"):
+            err = (out[key].cpu() - torch.from_numpy(golden[f"{name}.{key}"][t])).abs().max().item()
+            assert err < tol, f"{name} frame {t} {key}: {err:.2e}"
+
+
+def test_reference_frame_rule_matches_the_ids_the_reference_picked(golden):
+    from models.inference_io import sample_reference_ids
+    for name, v in VIDEOS.items():
+        ids = golden[f"{name}.clip_frame_ids"]
+        for t in range(v["n"]):
+            assert [t] + sample_reference_ids(t, list(range(v["n"])), v["R"]) == ids[t].tolist()
+
+
+@pytest.mark.parametrize("name,blocks", [("long_rgbd", (2, 3, 1, 3)), ("long_rgbd", (1,) * 9), ("long_rgbd", (9,)),
+                                         ("short_rgb", (2, 1)), ("exact_rgbd", (1, 3))])
+def test_video_stream_matches_the_reference_caller(golden, name, blocks, cpu_msda):
+    from models.clip_inference import ClipRunner, VideoStream
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    _patch_cpu_ops()
+    v = VIDEOS[name]
+    frames = video_frames(name)
+    det = build_detector(my_namespace(), v["R"], v["depth"])
+    stream = VideoStream(ClipRunner(det, micro_batch=2))
+    results, at, emitted_at = [], 0, {}
+    for i, b in enumerate(blocks):
+        got = stream.push(frames[at:at + b], last=(i == len(blocks) - 1))
+        at += b
+        for t, _ in got:
+            emitted_at[t] = at
+        results += got
+    _compare(name, results, golden)
+    # latency: a frame with R past frames is emitted with the block it arrives in; the first R wait for frame R (or the end)
+    for t, seen in emitted_at.items():
+        if t >= v["R"]:
+            assert seen - 1 < t + max(blocks), (t, seen)
+    assert not stream.pending and len(stream.bank) <= v["R"] + max(blocks) + 1
+
+
+def _worker(rank, world, port, name, out_path):
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    _patch_cpu_ops()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from models.clip_inference import ClipRunner, VideoStream
+        v = VIDEOS[name]
+        frames = video_frames(name)[:8]                       # 8 frames: blocks of 2 x 2 frames
+        det = build_detector(my_namespace(), v["R"], v["depth"])
+        stream = VideoStream(ClipRunner(det, micro_batch=2))
+        mine = []
+        for b in range(0, 8, 4):
+            block = frames[b + 2 * rank:b + 2 * rank + 2]
+            mine += stream.push(block, last=(b == 4))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [(t, {k: o[k] for k in o}) for t, o in mine])
+        if rank == 0:
+            torch.save(gathered, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_video_stream_on_two_ranks_matches_one_rank(tmp_path, cpu_msda):
+    """Two ranks over gloo, each pushing its 2 frames of every 4-frame block: together the outputs of the 8-frame video
+    equal the single-process stream's (the first 8 frames of the fixture's video with the video ENDING there)."""
+    from models.clip_inference import ClipRunner, VideoStream
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    port = 29900 + os.getpid() % 2000
+    path = str(tmp_path / "stream.pt")
+    mp.spawn(_worker, args=(2, port, "long_rgbd", path), nprocs=2, join=True)
+    sharded = {t: o for part in torch.load(path) for t, o in part}
+    _patch_cpu_ops()
+    v = VIDEOS["long_rgbd"]
+    stream = VideoStream(ClipRunner(build_detector(my_namespace(), v["R"], v["depth"]), micro_batch=2))
+    single = dict(stream.push(video_frames("long_rgbd")[:8], last=True))
+    assert sorted(sharded) == sorted(single) == list(range(8))
+    for t in range(8):
+        for k in ("pred_logits", "pred_boxes"):
+            assert torch.allclose(sharded[t][k], single[t][k], atol=1e-5), (t, k)

@@ -35,41 +35,8 @@ sys.path.insert(0, ROOT)
 import ref_import  # noqa: E402
 
 ref_import.install(roi_align_fn=None)
+ref = ref_import.import_inference()
 
-
-def _placeholder(name, **attrs):
-    m = types.ModuleType(name)
-    m.__dict__.update(attrs)
-    sys.modules[name] = m
-    return m
-
-
-class _Any:
-    def __init__(self, *a, **k):
-        pass
-
-    def __call__(self, *a, **k):
-        return self
-
-
-tv = sys.modules["torchvision"]
-tvt = _placeholder("torchvision.transforms", ToPILImage=_Any, Resize=_Any, Compose=_Any, ToTensor=_Any, Normalize=_Any)
-tvf = _placeholder("torchvision.transforms.functional", resize=lambda image, size: ("resized", tuple(size)))
-tvt.functional = tvf
-tv.transforms = tvt
-_placeholder("cv2")
-_placeholder("tqdm", tqdm=lambda x, *a, **k: x)
-mpl = _placeholder("matplotlib")
-mpl.pyplot = _placeholder("matplotlib.pyplot")
-pc = _placeholder("pycocotools")
-pc.coco = _placeholder("pycocotools.coco", COCO=_Any)
-pc.mask = _placeholder("pycocotools.mask")
-ds = _placeholder("datasets")
-ds.__path__ = []
-ds.coco_video_parser = _placeholder("datasets.coco_video_parser", CocoVID=_Any)
-sys.modules["models"].build_model = None                 # inference.py does ``from models import build_model``
-
-import inference as ref  # noqa: E402
 
 blobs = {}
 

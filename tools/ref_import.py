@@ -81,3 +81,43 @@ def install(roi_align_fn=None):
     mmod.MSDeformAttnFunction = FlatShim
     fmod.FlatShim = FlatShim
     return fmod
+
+
+def import_inference():
+    """The reference's inference.py as a module (after ``install``).  It imports cv2, pycocotools, matplotlib, tqdm and
+    torchvision.transforms at module level; none exists in this image and none is used by what the fixture generators call,
+    so they are satisfied by EMPTY placeholder modules (import-only names)."""
+    if "inference" in sys.modules:
+        return sys.modules["inference"]
+
+    def placeholder(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Any_:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+    tv = sys.modules["torchvision"]
+    tvt = placeholder("torchvision.transforms", ToPILImage=Any_, Resize=Any_, Compose=Any_, ToTensor=Any_, Normalize=Any_)
+    tvf = placeholder("torchvision.transforms.functional", resize=lambda image, size: ("resized", tuple(size)))
+    tvt.functional = tvf
+    tv.transforms = tvt
+    placeholder("cv2")
+    placeholder("tqdm", tqdm=lambda x, *a, **k: x)
+    mpl = placeholder("matplotlib")
+    mpl.pyplot = placeholder("matplotlib.pyplot")
+    pc = placeholder("pycocotools")
+    pc.coco = placeholder("pycocotools.coco", COCO=Any_)
+    pc.mask = placeholder("pycocotools.mask")
+    ds = placeholder("datasets")
+    ds.__path__ = []
+    ds.coco_video_parser = placeholder("datasets.coco_video_parser", CocoVID=Any_)
+    sys.modules["models"].build_model = None                 # inference.py does ``from models import build_model``
+    import inference
+    return inference
