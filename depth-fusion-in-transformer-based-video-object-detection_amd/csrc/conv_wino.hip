@@ -80,18 +80,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     int lb, cq = 0, tq = 0;
     if (CB == 2) {
         lb = g.lb0 + dfx::xcd_remap(blockIdx.x, gridDim.x);
-    } else {
+    } else if (CB == 1) {
         const int q = dfx::xcd_remap(blockIdx.x, gridDim.x);
         lb = g.lb0 + (q >> 2);
         cq = (q >> 1) & 1;
         tq = q & 1;
+    } else {
+        lb = dfx::xcd_remap(blockIdx.x, gridDim.x);          // <4,1>: 128 output channels x 32 tiles, g.ntb counts 32-tile blocks
     }
     const int cob = lb / g.ntb, tb = lb - cob * g.ntb;
-    const int co0 = cob * kCoB + cq * 32;
+    const int co0 = CB == 4 ? cob * 128 : cob * kCoB + cq * 32;
 
     // this thread's tile (the same tile for the input patch it loads and the outputs it writes) and input channel
     const int tl = tid % TW, cil = tid / TW;                  // (tid < X_ITEMS: patch loader)
-    const long t = (long)tb * kTB + tq * 32 + tl;
+    const long t = CB == 4 ? (long)tb * 32 + tl : (long)tb * kTB + tq * 32 + tl;
     const bool tv = t < g.tiles;
     const long tc = tv ? t : 0;
     const int per_img = g.TY * g.TX;
@@ -126,13 +128,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     const bool xloader = X_ITEMS == 512 || tid < X_ITEMS;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.X), 0, (int)g.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.U), 0, (int)g.ubytes, 0x00020000);
-    const unsigned ubase = (unsigned)cob * g.nchunk * (kUChunk * 4u);
+    const unsigned ubase = (unsigned)(co0 / kCoB) * g.nchunk * (kUChunk * 4u);
     // U: the chunk of the 64-channel block is [pos][kq][64 co][4]; this workgroup stages its CW channels of every row
+    // (128 channels = two neighbouring 64-channel blocks of the weight tensor)
     unsigned uoff[U_LD];
 #pragma unroll
     for (int i = 0; i < U_LD; ++i) {
-        const int f = tid + i * 512, row = f / CW, col = f % CW;
-        uoff[i] = (unsigned)((row * kCoB + cq * 32 + col) * 16);
+        const int f = tid + i * 512, row = f / CW, col = cq * 32 + f % CW;
+        uoff[i] = (unsigned)(col >> 6) * (unsigned)g.nchunk * (kUChunk * 4u) + (unsigned)((row * kCoB + (col & 63)) * 16);
     }
 
     f32x16 acc[2][CB][TB];      // [position][co tile][tile tile]
@@ -371,6 +374,18 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // One 512-thread workgroup per CU: the launch runs in rounds of 256 logical blocks.  A last round that would fill
     // at most ~60 % of the CUs is run as quarter-size workgroups instead (4 per block: ~0.3 of a round when they fit
     // the chip at once); a problem smaller than one round is all quarter-size.
+    // 128 output channels x 32 tiles per workgroup (conv_wino_kernel<4, 1>): every input patch is loaded and transformed for
+    // twice as many output channels, at the price of twice the (LDS-DMA staged) weight traffic; for Co % 128 == 0
+    static const char *wide_env = getenv("DFX_WINO_WIDE");
+    const bool wide = Co % 128 == 0 && (wide_env ? wide_env[0] == '1' : false);
+    if (wide) {
+        const long ntb32 = (g.tiles + 31) / 32;
+        g.ntb = (int)ntb32;
+        g.lb0 = 0;
+        const long wblocks = ntb32 * (Co / 128);
+        dfx::launch_timed(2L * 16 * 128 * Ci * 32 * wblocks, -3, dilation, conv_wino_kernel<4, 1>, dim3((unsigned)wblocks), dim3(512), 0, st, g);
+        return dfx::check_launch("conv_wino_kernel");
+    }
     const long rem = blocks % 256, full = blocks - rem;
     const bool quarter_tail = rem > 0 && rem <= 160 && !getenv("DFX_WINO_NO_TAIL");
     const long main_blocks = quarter_tail ? full : blocks;

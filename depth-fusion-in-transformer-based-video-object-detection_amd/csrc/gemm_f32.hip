@@ -49,6 +49,9 @@ struct Args {
     int wide_epilogue;    // row-major C (and R) with 16-byte aligned rows, N % 4 == 0: float4 epilogue through LDS
     int splits, kper;     // split-K: z = batch * splits + split, split s covers k in [s * kper, min(K, (s + 1) * kper))
     int nx, ny;           // tiles along N and M (the grid is one-dimensional: nx * ny * nz workgroups)
+    const float *B2;      // two-segment [K,N] operand: rows k >= K1 come from B2 (row k - K1), same ldb; LDS-DMA path only
+    long strideB2;
+    int K1;
     int group_m;          // tile order (placement only, never results): 0 = n fastest, then m, then z, as dispatched;
                           // > 0: workgroup ids are XCD-remapped (each XCD walks one contiguous range) and run m fastest inside
                           // groups of group_m tile rows, then along the columns of every batch element
@@ -136,7 +139,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     const long bytesB = B_KN ? ((long)(K - 1) * g.ldb + g.N) * 4 : ((long)(g.N - 1) * g.ldb + K) * 4;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A2 ? A2 : A), 0, (int)bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bytesB, 0x00020000);
+    // (two-segment operand: this descriptor covers rows 0 .. K1 - 1, rsB2 the rest)
+    const long bytesB1 = (B_KN && g.B2) ? ((long)(g.K1 - 1) * g.ldb + g.N) * 4 : bytesB;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (int)bytesB1, 0x00020000);
+    const float *Bsec = (B_KN && g.B2) ? g.B2 + bz * g.strideB2 : B;
+    const __amdgpu_buffer_rsrc_t rsB2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(Bsec), 0, (int)(((long)(g.K - g.K1 - 1) * g.ldb + g.N) * 4), 0x00020000);
     unsigned va[A_LOADS], vb[B_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -262,14 +270,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass cannot form an LDS-address-space pointer; it only needs the kernel's handle)
         typedef __attribute__((address_space(3))) void *lds_ptr;
         const unsigned sa = g.ablk_stride > 0 ? (unsigned)(k0 >> 2) * (unsigned)g.ablk_stride * 4u : (unsigned)k0 * 4u;
-        const unsigned sb = B_KN ? (unsigned)k0 * (unsigned)g.ldb * 4u : (unsigned)k0 * 4u;
+        const bool second = B_KN && g.B2 && k0 >= g.K1;             // (scalar: a K-step lies in one segment, K1 % BK == 0)
+        const unsigned sb = B_KN ? (unsigned)(second ? k0 - g.K1 : k0) * (unsigned)g.ldb * 4u : (unsigned)k0 * 4u;
         float *la = &As[buf][0][0], *lb = &Bs[buf][0];
 #pragma unroll
         for (int i = 0; i < A_PW; ++i)
             if (dpa[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(la + (wave_u + 4 * i) * 256), 16, dva[i], sa, 0, 0);
+        if (second) {
 #pragma unroll
-        for (int i = 0; i < B_PW; ++i)
-            if (dpb[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (wave_u + 4 * i) * 256), 16, dvb[i], sb, 0, 0);
+            for (int i = 0; i < B_PW; ++i)
+                if (dpb[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (lds_ptr)(lb + (wave_u + 4 * i) * 256), 16, dvb[i], sb, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_PW; ++i)
+                if (dpb[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (wave_u + 4 * i) * 256), 16, dvb[i], sb, 0, 0);
+        }
 #endif
     };
 
@@ -452,6 +467,11 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     // LDS-DMA staging unless the prologue add needs registers, K has a tail, or the kernel is the HBM-bound short-K
     // residual convolution (layer1 / layer2 conv3), where the DMA wait also drains the residual prefetch
     bool dma = !g.A2 && g.K % BK == 0 && kloc % BK == 0 && !(g.R && kloc <= 128) && !getenv("DFX_GEMM_NO_DMA");
+    if (g.B2) {
+        if (g.A2 || g.K % BK || g.K1 % BK || g.splits > 1 || !b_is_kn)
+            return dfx::fail(DFX_EINVAL, "gemm: a two-segment operand needs K and K1 multiples of %d, no A2, no split-K", BK);
+        dma = true;
+    }
     if (dma) {
         if (b_is_kn) dfx::launch_timed(flops, -1, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, true, BK, true>, grid, block, 0, st, g);
         else dfx::launch_timed(flops, -2, BM * 1000 + BN, gemm_f32_kernel<BM, BN, WM, WN, false, BK, true>, grid, block, 0, st, g);
@@ -496,6 +516,30 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
            M, N, K, relu, c_block, c_block_stride, a_block_stride, wide, 1, K};
     return choose_and_launch(g, batch, b_is_kn, static_cast<hipStream_t>(stream));
+}
+
+// Y[n] = act(W x [X1[n]; X2[n]] + bias): the last 1x1 convolution of a bottleneck and its stride-1 projection shortcut in
+// ONE product over the concatenated input channels (include/dfx_gemm.h)
+extern "C" int dfx_conv1x1_pair_f32(const float *W, const float *X1, long strideX1, int K1, const float *X2, long strideX2,
+                                    int K2, const float *bias, float *Y, long strideY, int Co, int HW, int batch, int act,
+                                    void *stream)
+{
+    if (Co < 0 || HW < 0 || K1 <= 0 || K2 <= 0 || batch < 0) return dfx::fail(DFX_EINVAL, "conv1x1_pair: bad dimension");
+    if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "conv1x1_pair: activation code must be 0, 1 or 2");
+    if ((long)Co * HW * batch == 0) return DFX_OK;
+    if (!W || !X1 || !X2 || !Y) return dfx::fail(DFX_EINVAL, "conv1x1_pair: null pointer");
+    const int K = K1 + K2;
+    if ((K1 & 15) || (K2 & 15) || (HW & 3) || (strideX1 & 3) || (strideX2 & 3) || (strideY & 3) || !dfx::aligned16(W) ||
+        !dfx::aligned16(X1) || !dfx::aligned16(X2) || !dfx::aligned16(Y))
+        return dfx::fail(DFX_EINVAL, "conv1x1_pair: channel counts must be multiples of 16, H*W of 4, buffers 16-byte aligned");
+    if (batch > 65535 || (long)Co * K * 4 >= (1L << 31) || (long)K1 * HW * 4 >= (1L << 31) || (long)K2 * HW * 4 >= (1L << 31))
+        return dfx::fail(DFX_ERANGE, "conv1x1_pair: an operand exceeds 2 GiB per image");
+    Args g{W, nullptr, (long)K, 0, X1, (long)HW, strideX1, bias, 1, nullptr, 0, 0, nullptr, 0, Y, (long)HW, strideY,
+           Co, HW, K, act, 0, 0, 0, 1, 1, K};
+    g.B2 = X2;
+    g.strideB2 = strideX2;
+    g.K1 = K1;
+    return choose_and_launch(g, batch, 1, static_cast<hipStream_t>(stream));
 }
 
 namespace {

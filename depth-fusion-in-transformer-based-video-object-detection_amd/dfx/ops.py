@@ -379,6 +379,26 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     return out
 
 
+def conv1x1_pair(x1, x2, weight, bias=None, relu=False):
+    """relu?(weight x [x1 ; x2] + bias): two NCHW inputs of one map size concatenated along the channels inside the
+    product (include/dfx_gemm.h, dfx_conv1x1_pair_f32) - a bottleneck's last 1x1 convolution and its stride-1
+    projection shortcut in one GEMM.  x1 [N,K1,H,W], x2 [N,K2,H,W], weight [Co,K1+K2] -> [N,Co,H,W]."""
+    lib = _lib.load()
+    _check_inputs([("x1", x1), ("x2", x2), ("weight", weight)] + ([("bias", bias)] if bias is not None else []))
+    Nb, K1, H, W = x1.shape
+    K2 = x2.shape[1]
+    Co = weight.shape[0]
+    _require(x1.dtype == torch.float32 and x2.shape == (Nb, K2, H, W) and weight.shape == (Co, K1 + K2),
+             "conv1x1_pair: x1 [N,K1,H,W], x2 [N,K2,H,W], weight [Co,K1+K2], fp32")
+    out = torch.empty((Nb, Co, H, W), dtype=x1.dtype, device=x1.device)
+    with torch.cuda.device(x1.device):
+        rc = lib.dfx_conv1x1_pair_f32(weight.data_ptr(), x1.data_ptr(), K1 * H * W, K1, x2.data_ptr(), K2 * H * W, K2,
+                                      _ptr(bias), out.data_ptr(), Co * H * W, Co, H * W, Nb, int(bool(relu)),
+                                      _stream(x1.device))
+    _lib.check(rc, "conv1x1_pair")
+    return out
+
+
 def dynamic_conv(feats, params, norm1, norm2):
     """relu(norm2(relu(norm1(feats @ k1)) @ k2)) per RoI with k1, k2 cut from ``params`` (include/dfx_roi.h,
     dfx_dynamic_conv_f32): feats [K,R,256] contiguous, params [K, 2*256*64] (rows may be strided), norm1 / norm2

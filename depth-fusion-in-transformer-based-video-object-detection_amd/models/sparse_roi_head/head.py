@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from models.fused import Linear
+from models.transformer_layers import _norm_add
 
 _DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
 
@@ -49,7 +50,7 @@ class DynamicConv(nn.Module):
             params2 = self.dynamic_layer(pro_features).view(feats.shape[0], -1)            # K, 2*C*dd
             feats = _ops.dynamic_conv(feats, params2, self.norm1, self.norm2)
             feats = self.out_layer(feats.flatten(1))
-            return self.activation(self.norm3(feats))
+            return self.activation(_norm_add(self.norm3, feats))
         params = self.dynamic_layer(pro_features).permute(1, 0, 2)          # K,1,2*C*dd
         k1 = params[:, :, : self.num_params].reshape(-1, self.hidden_dim, self.dim_dynamic)
         k2 = params[:, :, self.num_params:].reshape(-1, self.dim_dynamic, self.hidden_dim)
@@ -89,13 +90,13 @@ class RCNNHead(nn.Module):
             attn = fused_mha.forward(self.self_attn, pf, pf, pf).permute(1, 0, 2)           # nr,N,C
         else:
             attn = self.self_attn(q, q, value=q)[0]
-        q = self.norm1(q + self.dropout1(attn))
+        q = _norm_add(self.norm1, q, self.dropout1(attn))      # residual + LayerNorm in one pass on the GPU
         q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
-        obj = self.norm2(q + self.dropout2(self.inst_interact(q, roi)))
+        obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi)))
         if (self.activation is F.relu and obj.is_cuda and obj.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue
             hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
         else:
             hdn = self.activation(self.linear1(obj))
         y = self.linear2(self.dropout(hdn))
-        return self.norm3(obj + self.dropout3(y))
+        return _norm_add(self.norm3, obj, self.dropout3(y))

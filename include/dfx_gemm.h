@@ -37,6 +37,14 @@
  * K is cut into ``splits`` ranges of whole 16-deep steps that run as independent workgroups writing partial
  * [M,N] slabs to ``workspace`` (splits * M * N floats, caller-owned), followed by one reduction launch that
  * adds the slabs, bias, residual and applies the activation.  Row-major A [M,K], C [M,N]; N % 4 == 0.
+ *
+ * dfx_conv1x1_pair_f32: Y[n] = act(W x [X1[n] ; X2[n]] + bias) - two NCHW inputs of the same map size concatenated
+ * along the channels INSIDE the product: the last 1x1 convolution of a bottleneck and the stride-1 projection
+ * shortcut of the same block (torchvision Bottleneck: out = relu(bn3(conv3(t)) + downsample(x)),
+ * /root/reference/models/backbone_scratch.py:102-141 via resnet50's layer1[0] and the dilated layer4[0]) as ONE GEMM
+ * with W = [W3 | Wd] (frozen-BN scales folded in, bias = shift3 + shiftd): the shortcut map is neither written nor
+ * read back as a residual.  X1 [batch,K1,HW], X2 [batch,K2,HW] (image strides in floats), W [Co,K1+K2] row-major,
+ * Y [batch,Co,HW]; K1, K2 multiples of 16, HW of 4.
  */
 #ifndef DFX_GEMM_H
 #define DFX_GEMM_H
@@ -58,6 +66,10 @@ int dfx_gemm_splitk_f32(const float *A, long lda, const float *B, long ldb, int 
                         const float *bias, int bias_per_row, const float *R, long ldr,
                         float *C, long ldc, int M, int N, int K, int act, int splits,
                         float *workspace, void *stream);
+
+int dfx_conv1x1_pair_f32(const float *W, const float *X1, long strideX1, int K1,
+                         const float *X2, long strideX2, int K2, const float *bias,
+                         float *Y, long strideY, int Co, int HW, int batch, int act, void *stream);
 
 #ifdef __cplusplus
 }
