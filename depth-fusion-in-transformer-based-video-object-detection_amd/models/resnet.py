@@ -11,7 +11,11 @@ architecture; numerics are plain conv2d and pinned by torch.
 import torch
 from torch import nn
 
+import os
+
 from dfx import ops as _ops
+
+_PAIR_SHORTCUT = os.environ.get("DFX_PAIR_SHORTCUT", "1") == "1"      # A/B switch of the fused conv3 + shortcut product
 
 
 def _fold(conv, bn):
@@ -57,6 +61,14 @@ class Bottleneck(nn.Module):
                                   scale=scale2.detach(), groups=c2.groups, padding_mode=c2.padding_mode)
             f = [_fold(self.conv1, self.bn1), plan2, _fold(self.conv3, self.bn3)]
             f.append(_fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None)
+            # a stride-1 projection shortcut (layer1[0]; layer4[0] of the dilated DC5 stage) joins conv3 in ONE product over
+            # the concatenated input channels: W = [W3 | Wd], bias = shift3 + shiftd (dfx.ops.conv1x1_pair)
+            pair = None
+            if self.downsample is not None and self.downsample[0].stride[0] == 1 and _PAIR_SHORTCUT:
+                (w3, b3), (wd, bd) = f[2], f[3]
+                if w3.shape[1] % 16 == 0 and wd.shape[1] % 16 == 0:
+                    pair = (torch.cat([w3.flatten(1), wd.flatten(1)], 1).contiguous(), (b3 + bd).contiguous())
+            f.append(pair)
             self._folded = (key, f)
         return self._folded[1]
 
@@ -65,9 +77,11 @@ class Bottleneck(nn.Module):
         hand-written Winograd / implicit-GEMM kernels (dfx.ops.ConvPlan, csrc/conv_wino.hip,
         csrc/conv_igemm.hip), the 1x1 convolutions on the hand-written MFMA GEMM (dfx.ops.conv1x1), each
         with bias / residual / ReLU in its epilogue.  No CPU route."""
-        (w1, b1), plan2, (w3, b3), down = self._folded_params()
+        (w1, b1), plan2, (w3, b3), down, pair = self._folded_params()
         out = self._conv1x1(0, x, w1, b1, relu=True)
         out = plan2(out)
+        if pair is not None and (out.shape[2] * out.shape[3]) % 4 == 0 and out.shape[2:] == x.shape[2:]:
+            return _ops.conv1x1_pair(out, x.contiguous(), pair[0], pair[1], relu=True)
         if down is not None:
             x = self._conv1x1(1, x, down[0], down[1], relu=False, stride=self.downsample[0].stride[0])
         return self._conv1x1(2, out, w3, b3, relu=True, residual=x)

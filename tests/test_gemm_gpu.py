@@ -347,3 +347,22 @@ def test_conv_plan_runs_in_image_ranges_and_rejects_what_it_does_not_cover(monke
     for bad in (dict(stride=(1, 2)), dict(padding=(1, 0)), dict(dilation=(2, 1)), dict(groups=2), dict(padding_mode="reflect")):
         with pytest.raises(RuntimeError):
             ops.ConvPlan(wt, None, **bad)
+
+
+@pytest.mark.parametrize("K1,K2,Co,H,W,N", [(64, 64, 256, 20, 34, 3), (512, 1024, 2048, 10, 14, 2), (16, 32, 64, 6, 10, 1),
+                                            (128, 48, 200, 7, 12, 2)])
+def test_conv1x1_pair_matches_fp64(K1, K2, Co, H, W, N):
+    """relu(W x [x1 ; x2] + b) - a bottleneck's conv3 and its stride-1 projection shortcut as ONE product over the
+    concatenated channels (dfx_conv1x1_pair_f32: two-segment [K,N] operand, the K loop switches descriptor at K1)."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(K1 + K2 + Co)
+    x1 = torch.randn(N, K1, H, W, generator=g).cuda()
+    x2 = torch.randn(N, K2, H, W, generator=g).cuda()
+    w = (torch.randn(Co, K1 + K2, generator=g) / (K1 + K2) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    got = ops.conv1x1_pair(x1, x2, w, b, relu=True)
+    want = (torch.einsum("ok,nkhw->nohw", w.double(), torch.cat([x1, x2], 1).double()) + b.double().view(1, -1, 1, 1)).relu()
+    assert got.shape == (N, Co, H, W)
+    assert (got.double() - want).abs().max().item() < 4e-6 * (K1 + K2) ** 0.5
+    assert torch.equal(ops.conv1x1_pair(x1, x2, w, None, relu=False) + b.view(1, -1, 1, 1),
+                       ops.conv1x1(torch.cat([x1, x2], 1), w, None) + b.view(1, -1, 1, 1))
