@@ -26,8 +26,10 @@ class Linear(nn.Linear):
     MFMA GEMM with the bias in its epilogue (dfx.ops.linear, csrc/gemm_f32.hip); anything else is nn.Linear."""
 
     def forward(self, x):
+        # (under autocast, or with parameters in another dtype / on another device, this is plain nn.Linear)
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self.in_features % 4 == 0
-                and x.numel() > 0):
+                and x.numel() > 0 and self.weight.dtype == torch.float32 and self.weight.device == x.device
+                and not torch.is_autocast_enabled()):
             from dfx import ops
             return ops.linear(x.contiguous(), self.weight, self.bias)
         return super().forward(x)

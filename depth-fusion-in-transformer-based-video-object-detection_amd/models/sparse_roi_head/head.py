@@ -92,7 +92,7 @@ class RCNNHead(nn.Module):
             attn = self.self_attn(q, q, value=q)[0]
         q = _norm_add(self.norm1, q, self.dropout1(attn))      # residual + LayerNorm in one pass on the GPU
         q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
-        obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi)))
+        obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi)).view_as(q))
         if (self.activation is F.relu and obj.is_cuda and obj.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue
             hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)

@@ -121,3 +121,19 @@ def test_video_stream_on_two_ranks_matches_one_rank(tmp_path, cpu_msda):
     for t in range(8):
         for k in ("pred_logits", "pred_boxes"):
             assert torch.allclose(sharded[t][k], single[t][k], atol=1e-5), (t, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,blocks", [("long_rgbd", (2, 3, 1, 3)), ("short_rgb", (2, 1))])
+def test_video_stream_on_the_hip_path_matches_the_reference_caller(golden, name, blocks):
+    """The same stream on the GPU (HIP MSDA / RoIAlign / GEMM kernels, fused inference routes)."""
+    from models.clip_inference import ClipRunner, VideoStream
+    v = VIDEOS[name]
+    frames = video_frames(name).cuda()
+    det = build_detector(my_namespace(), v["R"], v["depth"]).cuda()
+    stream = VideoStream(ClipRunner(det, micro_batch=4))
+    results, at = [], 0
+    for i, b in enumerate(blocks):
+        results += stream.push(frames[at:at + b], last=(i == len(blocks) - 1))
+        at += b
+    _compare(name, results, golden)
