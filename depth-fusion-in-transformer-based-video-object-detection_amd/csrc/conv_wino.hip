@@ -59,6 +59,8 @@ constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk of a 64-
 // CB x TB = MFMA tiles (32 output channels x 32 Winograd tiles each) per workgroup and position.  <2,2> is the kernel
 // described above; <1,1> - a quarter of the output block, same 8 waves - covers the logical blocks that would
 // otherwise form a last, mostly empty round over the 256 CUs (and small problems altogether), sub-block by sub-block.
+// (Measured and dropped, round 3: <4,1> = 128 output channels x 32 tiles - half the patch loads / transforms per MFMA, twice
+// the LDS-DMA weight traffic, the full 160 KB of LDS - is 6-11 % slower on layer2-4, profiles/r03_wino_wide.txt.)
 template <int CB, int TB>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 {
@@ -80,20 +82,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     int lb, cq = 0, tq = 0;
     if (CB == 2) {
         lb = g.lb0 + dfx::xcd_remap(blockIdx.x, gridDim.x);
-    } else if (CB == 1) {
+    } else {
         const int q = dfx::xcd_remap(blockIdx.x, gridDim.x);
         lb = g.lb0 + (q >> 2);
         cq = (q >> 1) & 1;
         tq = q & 1;
-    } else {
-        lb = dfx::xcd_remap(blockIdx.x, gridDim.x);          // <4,1>: 128 output channels x 32 tiles, g.ntb counts 32-tile blocks
     }
     const int cob = lb / g.ntb, tb = lb - cob * g.ntb;
-    const int co0 = CB == 4 ? cob * 128 : cob * kCoB + cq * 32;
+    const int co0 = cob * kCoB + cq * 32;
 
     // this thread's tile (the same tile for the input patch it loads and the outputs it writes) and input channel
     const int tl = tid % TW, cil = tid / TW;                  // (tid < X_ITEMS: patch loader)
-    const long t = CB == 4 ? (long)tb * 32 + tl : (long)tb * kTB + tq * 32 + tl;
+    const long t = (long)tb * kTB + tq * 32 + tl;
     const bool tv = t < g.tiles;
     const long tc = tv ? t : 0;
     const int per_img = g.TY * g.TX;
@@ -374,18 +374,6 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // One 512-thread workgroup per CU: the launch runs in rounds of 256 logical blocks.  A last round that would fill
     // at most ~60 % of the CUs is run as quarter-size workgroups instead (4 per block: ~0.3 of a round when they fit
     // the chip at once); a problem smaller than one round is all quarter-size.
-    // 128 output channels x 32 tiles per workgroup (conv_wino_kernel<4, 1>): every input patch is loaded and transformed for
-    // twice as many output channels, at the price of twice the (LDS-DMA staged) weight traffic; for Co % 128 == 0
-    static const char *wide_env = getenv("DFX_WINO_WIDE");
-    const bool wide = Co % 128 == 0 && (wide_env ? wide_env[0] == '1' : false);
-    if (wide) {
-        const long ntb32 = (g.tiles + 31) / 32;
-        g.ntb = (int)ntb32;
-        g.lb0 = 0;
-        const long wblocks = ntb32 * (Co / 128);
-        dfx::launch_timed(2L * 16 * 128 * Ci * 32 * wblocks, -3, dilation, conv_wino_kernel<4, 1>, dim3((unsigned)wblocks), dim3(512), 0, st, g);
-        return dfx::check_launch("conv_wino_kernel");
-    }
     const long rem = blocks % 256, full = blocks - rem;
     const bool quarter_tail = rem > 0 && rem <= 160 && !getenv("DFX_WINO_NO_TAIL");
     const long main_blocks = quarter_tail ? full : blocks;
