@@ -29,6 +29,22 @@
 #include "dfx_conv.h"
 #include <stdlib.h>
 
+// Diagnostic build only (tools/wino_stamp.py compiles this file with -DDFX_WINO_STAMP into its own library): waves 0 and 4 of
+// a few workgroups record s_memtime at fixed points of every K-loop iteration into a buffer no other code reads.
+#ifdef DFX_WINO_STAMP
+__device__ unsigned long long *g_wino_stamps = nullptr;       // [block slot][wave 0 / 4][chunk][8]
+extern "C" int dfx_wino_set_stamp_buffer(void *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define WINO_STAMP(slot)                                                                                   \
+    do {                                                                                                   \
+        if (stamp_base && lane == 0) stamp_base[ch * 8 + (slot)] = __builtin_amdgcn_s_memtime();           \
+    } while (0)
+#else
+#define WINO_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -203,6 +219,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // chunk t, then load chunk t+2.  Either way chunk t+1 is complete at the barrier that ends iteration t, and the
     // buffer it goes to (that of chunk t-1) was released by the previous barrier.
     const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+#ifdef DFX_WINO_STAMP
+    unsigned long long *stamp_base = nullptr;
+    if (CB == 2 && g_wino_stamps && (wave == 0 || wave == 4) && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)
+        stamp_base = g_wino_stamps + ((blockIdx.x / 97) * 2 + (wave >> 2)) * (long)(g.nchunk * 8);
+#endif
     dma_u(0, 0);
     load_x(0);
     store_v(0);
@@ -211,8 +232,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     __syncthreads();
     for (int ch = 0; ch < g.nchunk; ++ch) {
         const int buf = ch & 1;
+        WINO_STAMP(0);
         if (late && ch + 1 < g.nchunk) store_v(buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        WINO_STAMP(1);
         // operand fragments of both positions up front (the second position's LDS reads complete under the first
         // position's MFMAs), and BEFORE the next chunk's loads: hipcc orders every LDS access that follows an LDS-DMA in
         // program order behind it (it cannot tell the two buffers apart), so the DMA is issued after the last read
@@ -231,6 +254,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
                 for (int j = 0; j < TB; ++j) bf[p][tt][j] = vb[tt * TW + j * 32];
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DFX_WINO_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        WINO_STAMP(2);
         if (ch + 1 < g.nchunk) dma_u(ch + 1, buf ^ 1);           // lands under the MFMAs below
         if (!late) {
             if (ch + 1 < g.nchunk) load_x(ch + 1);
@@ -238,6 +265,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             if (ch + 2 < g.nchunk) load_x(ch + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
+        WINO_STAMP(3);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -252,9 +280,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        WINO_STAMP(4);
         if (!late && ch + 1 < g.nchunk) store_v(buf ^ 1);
+        WINO_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the U chunk have landed ...
+        WINO_STAMP(6);
         __syncthreads();                            // ... and after the barrier so have everybody's
+        WINO_STAMP(7);
     }
 
     // ---- epilogue: meet in LDS, A^T M A, bias, activation ----

@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
             for (int i = 0; i < B_PW; ++i)
                 if (dpb[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(lb + (wave_u + 4 * i) * 256), 16, dvb[i], sb, 0, 0);
         }
+#else
+        (void)rsB2;
 #endif
     };
 
