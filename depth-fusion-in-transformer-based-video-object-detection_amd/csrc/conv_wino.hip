@@ -117,7 +117,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     const int rem = (int)(tc - (long)n * per_img);
     const int ty = rem / g.TX, tx = rem - ty * g.TX;
     const int d = g.dil;
-    const int y0 = (ty / d) * 2 * d + ty % d, x0 = (tx / d) * 2 * d + tx % d;
+    // a row's tiles are numbered sub-lattice by sub-lattice (dilation d: d interleaved lattices of step 2d), so that
+    // neighbouring lanes are neighbouring tiles OF ONE LATTICE: x0 differs by 2d, and a lane's left / right patch columns are
+    // its neighbours' own columns
+    const int txl = g.TX / d;
+    const int y0 = (ty / d) * 2 * d + ty % d, x0 = (tx % txl) * 2 * d + tx / txl;
 
     // input patch: clamped row / column offsets + validity bits
     int roff[4], coff[4];
@@ -133,13 +137,23 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     const int HW = g.H * g.W;
     // buffer loads: wave-uniform descriptor (base, size) + per-lane 32-bit byte offset + scalar chunk offset
     // (checked on the host: the whole input < 2^32 bytes); 16 offset registers, no 64-bit address arithmetic
-    unsigned xoff[16];
+    // Patch loads.  A thread fetches only the two columns of its patch that no neighbour owns - x0 and x0 + d, for d = 1 one
+    // 8-byte load per row - and takes column x0 - d from the lane below and x0 + 2d from the lane above (v_mov_b32_dpp
+    // wave_shr / wave_shl): every input pixel is requested once per row of tiles instead of twice, in 4 (d = 1) or 8 vector
+    // memory instructions per chunk instead of 16.  (Measured with tools/wino_stamp.py: a wave spent 1100-1400 of its
+    // ~3400 cycles per chunk ISSUING the 16 dword gathers + 4 LDS-DMA pieces, and on this chip every cycle a wave spends
+    // outside its fp32 MFMAs is lost to the matrix pipe: the fp32 MFMA runs on the vector lanes.)  The first and the last
+    // lane of a run of tiles fetch their outer column themselves (one more load per row, two lanes active).
+    unsigned xo0[4], xo1[4], xoe[4];
+    const bool edge_lo = tl == 0, edge_hi = tl == TW - 1;
     {
         const unsigned b = (unsigned)((long)n * g.strideX) + (unsigned)((cil & (kCK - 1)) * HW);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xoff[i * 4 + j] = (b + (unsigned)(roff[i] + coff[j])) * 4u;
+        for (int i = 0; i < 4; ++i) {
+            xo0[i] = (b + (unsigned)(roff[i] + coff[1])) * 4u;
+            xo1[i] = (b + (unsigned)(roff[i] + coff[2])) * 4u;
+            xoe[i] = (b + (unsigned)(roff[i] + (edge_lo ? coff[0] : coff[3]))) * 4u;
+        }
     }
     const bool xloader = X_ITEMS == 512 || tid < X_ITEMS;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.X), 0, (int)g.xbytes, 0x00020000);
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
 
-    float xr[16];
+    float own0[4], own1[4], oute[4];       // columns x0, x0 + d and (edge lanes) the outer column, rows y0 - d .. y0 + 2d
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // U chunk: memory -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, U_LD per wave): the
     // staged image is lane-linear, so no registers and no ds_write are spent on the weights (half of the chunk's bytes)
@@ -183,12 +197,41 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     auto load_x = [&](int ch) {
         const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offset
         if (xloader) {
+            if (d == 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[i], xs, 0));
+                for (int i = 0; i < 4; ++i) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo0[i], xs, 0);
+                    own0[i] = __builtin_bit_cast(float, v[0]);
+                    own1[i] = __builtin_bit_cast(float, v[1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    own0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0[i], xs, 0));
+                    own1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo1[i], xs, 0));
+                }
+            }
+            if (edge_lo || edge_hi) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) oute[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoe[i], xs, 0));
+            }
         }
     };
     auto store_v = [&](int buf) {
         if (!xloader) return;
+        // the patch: [left neighbour's x0' + d | own x0 | own x0 + d | right neighbour's x0'']
+        float xr[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own1[i]), 0x138, 0xf, 0xf, false));  // wave_shr:1
+            float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own0[i]), 0x130, 0xf, 0xf, false));  // wave_shl:1
+            if (edge_lo) lo = oute[i];
+            if (edge_hi) hi = oute[i];
+            xr[i * 4 + 0] = lo;
+            xr[i * 4 + 1] = own0[i];
+            xr[i * 4 + 2] = own1[i];
+            xr[i * 4 + 3] = hi;
+        }
         // B^T d B
         float dd[16], tm[16];
 #pragma unroll
