@@ -77,7 +77,7 @@ constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk of a 64-
 // otherwise form a last, mostly empty round over the 256 CUs (and small problems altogether), sub-block by sub-block.
 // (Measured and dropped, round 3: <4,1> = 128 output channels x 32 tiles - half the patch loads / transforms per MFMA, twice
 // the LDS-DMA weight traffic, the full 160 KB of LDS - is 6-11 % slower on layer2-4, profiles/r03_wino_wide.txt.)
-template <int CB, int TB>
+template <int CB, int TB, bool D1>          // D1: dilation 1 (a lane's own two patch columns are adjacent: one 8-byte load per row)
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 {
     constexpr int CW = 32 * CB, TW = 32 * TB;                 // output channels / tiles of the workgroup
@@ -152,7 +152,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         for (int i = 0; i < 4; ++i) {
             xo0[i] = (b + (unsigned)(roff[i] + coff[1])) * 4u;
             xo1[i] = (b + (unsigned)(roff[i] + coff[2])) * 4u;
-            xoe[i] = (b + (unsigned)(roff[i] + (edge_lo ? coff[0] : coff[3]))) * 4u;
+            // (every lane issues the outer-column load; the inner lanes carry an offset beyond the buffer, for which the
+            // hardware's range check returns 0 without a memory access - a branch around the load would make hipcc wrap it
+            // in a waterfall loop behind an s_waitcnt vmcnt(0))
+            xoe[i] = (edge_lo || edge_hi) ? (b + (unsigned)(roff[i] + (edge_lo ? coff[0] : coff[3]))) * 4u : 0x80000000u;
         }
     }
     const bool xloader = X_ITEMS == 512 || tid < X_ITEMS;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     auto load_x = [&](int ch) {
         const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offset
         if (xloader) {
-            if (d == 1) {
+            if (D1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo0[i], xs, 0);
@@ -211,10 +214,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
                     own1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo1[i], xs, 0));
                 }
             }
-            if (edge_lo || edge_hi) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) oute[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoe[i], xs, 0));
-            }
+            for (int i = 0; i < 4; ++i) oute[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoe[i], xs, 0));
         }
     };
     auto store_v = [&](int buf) {
@@ -457,15 +458,23 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // included) in the byte field, tag_a = -3, tag_b = dilation; the direct form's flops are 2.25x as many
     if (main_blocks > 0) {
         g.lb0 = 0;
-        dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2>, dim3((unsigned)main_blocks),
-                          dim3(512), 0, st, g);
+        if (dilation == 1)
+            dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2, true>, dim3((unsigned)main_blocks),
+                              dim3(512), 0, st, g);
+        else
+            dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2, false>, dim3((unsigned)main_blocks),
+                              dim3(512), 0, st, g);
         const int rc = dfx::check_launch("conv_wino_kernel");
         if (rc != DFX_OK) return rc;
     }
     if (quarter_tail) {
         g.lb0 = (int)full;
-        dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1>, dim3((unsigned)(rem * 4)), dim3(512), 0,
-                          st, g);
+        if (dilation == 1)
+            dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1, true>, dim3((unsigned)(rem * 4)), dim3(512), 0,
+                              st, g);
+        else
+            dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1, false>, dim3((unsigned)(rem * 4)), dim3(512), 0,
+                              st, g);
     }
     return dfx::check_launch("conv_wino_kernel");
 }
