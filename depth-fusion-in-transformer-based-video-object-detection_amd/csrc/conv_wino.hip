@@ -77,7 +77,7 @@ constexpr int kUChunk = 16 * 2 * kCoB * 4;        // floats per U chunk of a 64-
 // otherwise form a last, mostly empty round over the 256 CUs (and small problems altogether), sub-block by sub-block.
 // (Measured and dropped, round 3: <4,1> = 128 output channels x 32 tiles - half the patch loads / transforms per MFMA, twice
 // the LDS-DMA weight traffic, the full 160 KB of LDS - is 6-11 % slower on layer2-4, profiles/r03_wino_wide.txt.)
-template <int CB, int TB, bool D1>          // D1: dilation 1 (a lane's own two patch columns are adjacent: one 8-byte load per row)
+template <int CB, int TB>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
 {
     constexpr int CW = 32 * CB, TW = 32 * TB;                 // output channels / tiles of the workgroup
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // (checked on the host: the whole input < 2^32 bytes); 16 offset registers, no 64-bit address arithmetic
     // Patch loads.  A thread fetches only the two columns of its patch that no neighbour owns - x0 and x0 + d, for d = 1 one
     // 8-byte load per row - and takes column x0 - d from the lane below and x0 + 2d from the lane above (v_mov_b32_dpp
-    // wave_shr / wave_shl): every input pixel is requested once per row of tiles instead of twice, in 4 (d = 1) or 8 vector
+    // wave_shr / wave_shl): every input pixel is requested once per row of tiles instead of twice, in 8 + 4 vector
     // memory instructions per chunk instead of 16.  (Measured with tools/wino_stamp.py: a wave spent 1100-1400 of its
     // ~3400 cycles per chunk ISSUING the 16 dword gathers + 4 LDS-DMA pieces, and on this chip every cycle a wave spends
     // outside its fp32 MFMAs is lost to the matrix pipe: the fp32 MFMA runs on the vector lanes.)  The first and the last
@@ -200,19 +200,12 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     auto load_x = [&](int ch) {
         const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offset
         if (xloader) {
-            if (D1) {
+            // (two dword loads also for d = 1, where the columns are adjacent: hipcc of ROCm 7.2 lowers
+            // __builtin_amdgcn_raw_buffer_load_b64 to a single buffer_load_dword - the upper half is never loaded)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(xrs, xo0[i], xs, 0);
-                    own0[i] = __builtin_bit_cast(float, v[0]);
-                    own1[i] = __builtin_bit_cast(float, v[1]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    own0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0[i], xs, 0));
-                    own1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo1[i], xs, 0));
-                }
+            for (int i = 0; i < 4; ++i) {
+                own0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0[i], xs, 0));
+                own1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo1[i], xs, 0));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) oute[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoe[i], xs, 0));
@@ -458,23 +451,15 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // included) in the byte field, tag_a = -3, tag_b = dilation; the direct form's flops are 2.25x as many
     if (main_blocks > 0) {
         g.lb0 = 0;
-        if (dilation == 1)
-            dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2, true>, dim3((unsigned)main_blocks),
-                              dim3(512), 0, st, g);
-        else
-            dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2, false>, dim3((unsigned)main_blocks),
-                              dim3(512), 0, st, g);
+        dfx::launch_timed(flops_per_block * main_blocks, -3, dilation, conv_wino_kernel<2, 2>, dim3((unsigned)main_blocks),
+                          dim3(512), 0, st, g);
         const int rc = dfx::check_launch("conv_wino_kernel");
         if (rc != DFX_OK) return rc;
     }
     if (quarter_tail) {
         g.lb0 = (int)full;
-        if (dilation == 1)
-            dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1, true>, dim3((unsigned)(rem * 4)), dim3(512), 0,
-                              st, g);
-        else
-            dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1, false>, dim3((unsigned)(rem * 4)), dim3(512), 0,
-                              st, g);
+        dfx::launch_timed(flops_per_block * rem, -3, dilation, conv_wino_kernel<1, 1>, dim3((unsigned)(rem * 4)), dim3(512), 0,
+                          st, g);
     }
     return dfx::check_launch("conv_wino_kernel");
 }
