@@ -135,27 +135,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         coff[i] = min(max(xx, 0), g.W - 1);
     }
     const int HW = g.H * g.W;
-    // buffer loads: wave-uniform descriptor (base, size) + per-lane 32-bit byte offset + scalar chunk offset
-    // (checked on the host: the whole input < 2^32 bytes); 16 offset registers, no 64-bit address arithmetic
-    // Patch loads.  A thread fetches only the two columns of its patch that no neighbour owns - x0 and x0 + d, for d = 1 one
-    // 8-byte load per row - and takes column x0 - d from the lane below and x0 + 2d from the lane above (v_mov_b32_dpp
-    // wave_shr / wave_shl): every input pixel is requested once per row of tiles instead of twice, in 8 + 4 vector
-    // memory instructions per chunk instead of 16.  (Measured with tools/wino_stamp.py: a wave spent 1100-1400 of its
-    // ~3400 cycles per chunk ISSUING the 16 dword gathers + 4 LDS-DMA pieces, and on this chip every cycle a wave spends
-    // outside its fp32 MFMAs is lost to the matrix pipe: the fp32 MFMA runs on the vector lanes.)  The first and the last
-    // lane of a run of tiles fetch their outer column themselves (one more load per row, two lanes active).
+    // Patch loads: buffer loads through a wave-uniform descriptor (base, size) with a per-lane 32-bit byte offset and the
+    // chunk's scalar offset; no 64-bit address arithmetic.  A thread fetches only the two columns of its patch that no
+    // neighbour owns - x0 and x0 + d - and takes column x0 - d from the lane below and x0 + 2d from the lane above
+    // (v_mov_b32_dpp wave_shr / wave_shl): every input pixel is requested once per row of tiles instead of twice, in 8 + 4
+    // vector memory instructions per chunk instead of 16.  The first and the last lane of a run of tiles fetch their outer
+    // column themselves: every lane issues that load, the inner lanes with an offset beyond the buffer (a branch around it
+    // makes hipcc wrap the load in a waterfall loop behind an s_waitcnt vmcnt(0)).  Taps outside the map carry the same
+    // out-of-range offset, for which the hardware's range check returns 0 without a memory access: no clamp, no select.
+    // Why the instruction count matters (tools/wino_stamp.py): the fp32 MFMA runs on the vector lanes, so every cycle a wave
+    // spends issuing anything else is lost to the matrix pipe; of its ~3400 cycles per chunk a wave spent 1100-1400 issuing
+    // the 16 dword gathers + 4 LDS-DMA pieces of the first version.
+    constexpr unsigned kOut = 0xFFFFFFFCu;          // >= the descriptor's extent (the host keeps the input below 2^32 - 4 bytes)
     unsigned xo0[4], xo1[4], xoe[4];
     const bool edge_lo = tl == 0, edge_hi = tl == TW - 1;
+    const bool col0 = (okbits >> 4) & 1u, col3 = (okbits >> 7) & 1u;      // x0 - d / x0 + 2d inside the map
     {
         const unsigned b = (unsigned)((long)n * g.strideX) + (unsigned)((cil & (kCK - 1)) * HW);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xo0[i] = (b + (unsigned)(roff[i] + coff[1])) * 4u;
-            xo1[i] = (b + (unsigned)(roff[i] + coff[2])) * 4u;
-            // (every lane issues the outer-column load; the inner lanes carry an offset beyond the buffer, for which the
-            // hardware's range check returns 0 without a memory access - a branch around the load would make hipcc wrap it
-            // in a waterfall loop behind an s_waitcnt vmcnt(0))
-            xoe[i] = (edge_lo || edge_hi) ? (b + (unsigned)(roff[i] + (edge_lo ? coff[0] : coff[3]))) * 4u : 0x80000000u;
+            const bool row = (okbits >> i) & 1u;
+            xo0[i] = (row && ((okbits >> 5) & 1u)) ? (b + (unsigned)(roff[i] + coff[1])) * 4u : kOut;
+            xo1[i] = (row && ((okbits >> 6) & 1u)) ? (b + (unsigned)(roff[i] + coff[2])) * 4u : kOut;
+            xoe[i] = (row && ((edge_lo && col0) || (edge_hi && col3))) ? (b + (unsigned)(roff[i] + (edge_lo ? coff[0] : coff[3]))) * 4u : kOut;
         }
     }
     const bool xloader = X_ITEMS == 512 || tid < X_ITEMS;
@@ -219,20 +221,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         for (int i = 0; i < 4; ++i) {
             float lo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own1[i]), 0x138, 0xf, 0xf, false));  // wave_shr:1
             float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own0[i]), 0x130, 0xf, 0xf, false));  // wave_shl:1
+            // a neighbour's value stands for an out-of-map column only at the ends of a row of tiles (the lane below / above
+            // then belongs to another row): zero there; everything a lane loaded itself is already zero outside the map
             if (edge_lo) lo = oute[i];
             if (edge_hi) hi = oute[i];
-            xr[i * 4 + 0] = lo;
+            xr[i * 4 + 0] = col0 ? lo : 0.f;
             xr[i * 4 + 1] = own0[i];
             xr[i * 4 + 2] = own1[i];
-            xr[i * 4 + 3] = hi;
+            xr[i * 4 + 3] = col3 ? hi : 0.f;
         }
         // B^T d B
-        float dd[16], tm[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                dd[i * 4 + j] = ((okbits >> i) & (okbits >> (4 + j)) & 1u) ? xr[i * 4 + j] : 0.f;
+        float tm[16];
+        const float *dd = xr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tm[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
@@ -421,7 +421,7 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     if (!x || !u || !y) return dfx::fail(DFX_EINVAL, "conv3x3_wino: null pointer");
     if (Ci % kCK || Co % kCoB) return dfx::fail(DFX_EINVAL, "conv3x3_wino: Ci must be a multiple of 8, Co of 64");
     if (!dfx::aligned16(u)) return dfx::fail(DFX_EINVAL, "conv3x3_wino: u must be 16-byte aligned");
-    if ((long)N * Ci * H * W >= (1L << 30) || (long)Co * H * W >= (1L << 31))
+    if ((long)N * Ci * H * W >= (1L << 30) - 1 || (long)Co * H * W >= (1L << 31))
         return dfx::fail(DFX_ERANGE, "conv3x3_wino: input exceeds 2^30 elements (split the batch)");
     if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "conv3x3_wino: unknown activation");
     WinoArgs g{};
