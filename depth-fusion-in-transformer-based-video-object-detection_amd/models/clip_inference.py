@@ -159,7 +159,7 @@ class ClipRunner:
             for sl in slices:
                 tail(encode(sl))
         meta = meta[-1]
-        out = {k: torch.cat(v, 0) for k, v in keep.items()}
+        out = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in keep.items()}      # (cat of ONE tensor is a copy)
         out["spatial_shapes"], out["level_start_index"] = meta
         if overlapped:
             out["_held"] = held       # keeps the cross-stream tensors alive until the caller drops the result
