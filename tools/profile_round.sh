@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round-2 evidence in one GPU call: bash tools/profile_round.sh   (writes under gpurun_out/r02/)
+# Round evidence in one GPU call: ROUND=r03 bash tools/profile_round.sh   (writes under gpurun_out/$ROUND/)
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+ROUND=${ROUND:-r03}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1; echo "stats done"
@@ -16,6 +17,9 @@ FRAMES=8 python3 $R/tools/bench_gemm.py > $O/bench_gemm_F8.txt 2>&1
 FRAMES=32 python3 $R/tools/bench_conv.py > $O/bench_conv_F32.txt 2>&1
 FRAMES=8 python3 $R/tools/bench_conv.py > $O/bench_conv_F8.txt 2>&1; echo "micro done"
 CASES="[(32,32,False),(16,16,False),(8,8,False),(4,4,False)]" python3 $R/tools/rank_step.py > $O/rank_step.txt 2>&1
+python3 $R/tools/proto_bf16x3.py > $O/proto_bf16x3.txt 2>&1
+python3 $R/tools/wino_stamp.py > $O/wino_stamp.txt 2>&1
+python3 $R/tools/memcpy_origins.py 4 > $O/memcpy_origins_f4.txt 2>&1
 python3 $R/tools/stage_times.py 32 > $O/stage_times_mb32.txt 2>&1
 python3 $R/tools/conv_error.py > $O/conv_error.txt 2>&1
 python3 $R/tools/level_time.py 2.5 > $O/level_time.txt 2>&1
@@ -24,7 +28,7 @@ python3 $R/tools/launch_bound.py > $O/launch_bound.txt 2>&1; echo "all done"
 # the raw per-dispatch CSVs are large: keep the summaries
 rm -f $O/stats/*kernel_trace.csv $O/stats_p0/*kernel_trace.csv
 cat > $O/pmc_kernels_table.md <<'HDR'
-# PMC counters of the hand-written MFMA kernels, 32 frames (round 2)
+# PMC counters of the hand-written MFMA kernels, 32 frames (round 3)
 
 Three `rocprofv3 --kernel-trace --pmc ... --output-format csv` passes over `tools/pmc_kernels.py` (one counter set per pass, as
 `MI355X_MICROARCH.md` prescribes; no `--stats`, no tracing domains), tabulated by `tools/pmc_report.py`:
@@ -43,7 +47,7 @@ Kernel times are under the counters (5-15 % slower than unprofiled).
 HDR
 python3 $R/tools/pmc_report.py $O/pmc1 $O/pmc2 $O/pmc3 >> $O/pmc_kernels_table.md 2>&1
 cat > $O/pmc_traffic_table.md <<'HDR'
-# Fabric-side traffic of the bench's kernel families (round 2)
+# Fabric-side traffic of the bench's kernel families (round 3)
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --pipeline 0 --steps 2 --warmup 1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --pipeline 0 --steps 2 --warmup 1
