@@ -67,8 +67,8 @@ torch.backends.cudnn.allow_tf32 = False
 # factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
 MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
 # fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
-# family's launches per step, from the PMC passes over this workload committed in profiles/r02_pmc_traffic.md
-FAMILY_TRAFFIC_PER_STEP = {"gemm": (197789.0e6, 212), "wino": (18836.2e6, 28), "igemm": (33042.7e6, 9)}
+# family's launches per step, from the PMC passes over this workload committed in profiles/r03_pmc_traffic.md
+FAMILY_TRAFFIC_PER_STEP = {"gemm": (101183.9e6, 210), "wino": (18905.2e6, 28), "igemm": (33025.4e6, 9)}
 
 # per-frame algorithmic work of config E in all-current mode and the one-pass bytes of the kernel families: generated by
 # tools/algorithmic_work.py (a walk over the built model at 800x1333) into tools/algorithmic_work.json; BASELINE.md
@@ -411,7 +411,7 @@ def main():
                                 if full_size else None),
                     "algorithmic_bytes": int(family_bytes("gemm", rank_frames) / (len(gemm) / steps_profiled)) if full_size else None,
                     "traffic_source": "PMC 2 x FETCH_SIZE + WRITE_SIZE (HBM + Infinity Cache side of L2), average per launch of "
-                                      "the family, profiles/r02_pmc_traffic.md",
+                                      "the family, profiles/r03_pmc_traffic.md",
                     "algorithmic_source": "tools/algorithmic_work.py: one-pass bytes of every 1x1 convolution and Linear of a step "
                                           "(inputs + outputs + weights + bottleneck residual reads), average per launch",
                     "launches": len(gemm), "flops_per_launch": wsum / len(gemm), "avg_launch_us": round(tsum / len(gemm) * 1e6, 2),
