@@ -41,7 +41,11 @@ __device__ __forceinline__ float activate(float v, int act)
     return v;
 }
 
-template <int BM, int WM, int WN>
+// UT ("uniform tap"): Ci % 16 == 0, so the 16 k of a K-step are 16 input channels of ONE tap: one table entry, one validity
+// test and one offset select per K-step instead of eight of each, the eight loads differ in their scalar offset only.  (The
+// fp32 MFMA shares the vector lanes - DESIGN.md section 7 - so the ~50 vector instructions and 7 scalar loads this removes
+// per K-step were matrix time.)  Everything but the 7x7 stem and the 1-channel DFormer stem takes this path.
+template <int BM, int WM, int WN, bool UT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
 {
     constexpr int BN = 128, BK = 16;
@@ -112,11 +116,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, va[i], 0, 0));
             va[i] += BK * 4u;
         }
+        if (UT) {
+            const int2 e = g.ktab[k0 + kb];                              // scalar load: k is wave-uniform
+            const unsigned vo = ((taps >> (e.x & 63)) & 1ull) ? vx : kOut;
+            const int cstep = 2 * HW * 4;                                // k advances by 2 per row of this thread: 2 channels
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) {
-            const int2 e = g.ktab[k0 + kb + 2 * i];                  // scalar load: k is wave-uniform
-            const bool ok = e.x >= 0 && ((taps >> (e.x & 63)) & 1ull);
-            rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, ok ? vx : kOut, e.y, 0));
+            for (int i = 0; i < B_ROWS; ++i)
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, e.y + i * cstep, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i) {
+                const int2 e = g.ktab[k0 + kb + 2 * i];                  // scalar load: k is wave-uniform
+                const bool ok = e.x >= 0 && ((taps >> (e.x & 63)) & 1ull);
+                rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, ok ? vx : kOut, e.y, 0));
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -220,7 +233,11 @@ int launch(const IgemmArgs &g, int N, hipStream_t st)
 {
     const dim3 grid((g.Ho * g.Wo + 127) / 128, (g.Co + BM - 1) / BM, N), block(256);
     // measurement aid (dfx_profile_*): flops of the launch (K padding included) in the byte field, tag_a = -4
-    dfx::launch_timed(2L * g.Co * g.Kpad * g.Ho * g.Wo * N, -4, BM, conv_igemm_kernel<BM, WM, WN>, grid, block, 0, st, g);
+    const long flops = 2L * g.Co * g.Kpad * g.Ho * g.Wo * N;
+    if (g.Ci % 16 == 0 && g.Kpad == g.KH * g.KW * g.Ci)
+        dfx::launch_timed(flops, -4, BM, conv_igemm_kernel<BM, WM, WN, true>, grid, block, 0, st, g);
+    else
+        dfx::launch_timed(flops, -4, BM, conv_igemm_kernel<BM, WM, WN, false>, grid, block, 0, st, g);
     return dfx::check_launch("conv_igemm_kernel");
 }
 
