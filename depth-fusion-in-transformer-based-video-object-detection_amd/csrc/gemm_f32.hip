@@ -52,6 +52,9 @@ struct Args {
     const float *B2;      // two-segment [K,N] operand: rows k >= K1 come from B2 (row k - K1), same ldb; LDS-DMA path only
     long strideB2;
     int K1;
+    const float *ln_g, *ln_b;   // LayerNorm over the N columns after the epilogue's bias / activation / residual (N == BN == 256)
+    float ln_eps;
+    int act_first;        // the activation applies before the residual is added (y = LN(R + act(A x B + bias)))
     int group_m;          // tile order (placement only, never results): 0 = n fastest, then m, then z, as dispatched;
                           // > 0: workgroup ids are XCD-remapped (each XCD walks one contiguous range) and run m fastest inside
                           // groups of group_m tile rows, then along the columns of every batch element
@@ -63,7 +66,7 @@ __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: 
 }
 
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK, bool DMA>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
+__global__ __launch_bounds__(256, (BM == 64 && BN == 256) ? 3 : 1) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int LDK = BK + 4;                       // [m][k] / [n][k] pitch: 5 (BK = 16) sixteen-byte slots
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
     static_assert(BK % 8 == 0, "a ds_read_b128 covers 8 consecutive k (4 per lane half)");
     // one LDS object: the two operand stages, re-used by the epilogue as a [64][BN + 4] transpose buffer
     constexpr int A_SZ = BM * LDK, B_SZ = B_KN ? BK * LDB : BN * LDK;               // floats per stage
-    constexpr int LDC = BN + 4, C_SZ = 64 * LDC;
+    constexpr int PR = BN >= 256 ? 32 : 64;           // tile rows per epilogue pass through LDS
+    constexpr int LDC = BN + 4, C_SZ = PR * LDC;
     constexpr int S_SZ = 2 * (A_SZ + B_SZ) > C_SZ ? 2 * (A_SZ + B_SZ) : C_SZ;
     __shared__ __attribute__((aligned(16))) float smem[S_SZ];
     float (*const As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(smem);        // As[buf][m][k]
@@ -377,13 +381,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
         // quarter of the memory instructions.  The convolutions with many output channels and a short K
         // (Bottleneck.conv3 + residual) are bound by exactly this traffic.
         float *Ct = smem;
+        const bool ln = BN == 256 && g.ln_g != nullptr;       // (a wave-instruction of the float4 loop covers one whole row)
 #pragma unroll
-        for (int p = 0; p < BM / 64; ++p) {
+        for (int p = 0; p < BM / PR; ++p) {
             if (p > 0) __syncthreads();
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if ((wm * TM + i * 32) / 64 != p) continue;           // wave-uniform
-                const int rbase = wm * TM + i * 32 - p * 64 + 4 * half;
+                if ((wm * TM + i * 32) / PR != p) continue;           // wave-uniform
+                const int rbase = wm * TM + i * 32 - p * PR + 4 * half;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -391,20 +396,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Args g)
                         Ct[(rbase + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
             }
             __syncthreads();
-            constexpr int F4 = 64 * BN / 4;
+            constexpr int F4 = PR * BN / 4;
 #pragma unroll
             for (int f0 = 0; f0 < F4; f0 += 256) {
                 const int f = f0 + tid;
                 if (F4 % 256 != 0 && f >= F4) break;
                 const int row = f / (BN / 4), c4 = f % (BN / 4);
-                const int m = m0 + p * 64 + row, n = n0 + c4 * 4;
+                const int m = m0 + p * PR + row, n = n0 + c4 * 4;
                 if (m >= g.M || n >= g.N) continue;
                 float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
                 if (brow) { const float b = g.bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
                 if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (g.relu && g.act_first) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
                 if (PREFETCH_R && use_rpre) { const f32x4 q = rpre[PREFETCH_R ? f0 / 256 : 0]; v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
                 else if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-                if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
+                if (g.relu && !g.act_first) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
+                if (ln) {
+                    // LayerNorm of the row the wave holds (64 lanes x 4 columns): mean, then the centred second moment
+                    float sum = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    const float mean = sum * (1.f / 256.f);
+                    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+                    float sq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+                    const float rstd = 1.f / sqrtf(sq * (1.f / 256.f) + g.ln_eps);
+                    const float4 gm = *reinterpret_cast<const float4 *>(g.ln_g + n), bt = *reinterpret_cast<const float4 *>(g.ln_b + n);
+                    v.x = v.x * rstd * gm.x + bt.x; v.y = v.y * rstd * gm.y + bt.y;
+                    v.z = v.z * rstd * gm.z + bt.z; v.w = v.w * rstd * gm.w + bt.w;
+                }
                 if (mask && mask[m]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(C + (long)m * g.ldc + n) = v;
             }
@@ -518,6 +539,34 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
            M, N, K, relu, c_block, c_block_stride, a_block_stride, wide, 1, K};
     return choose_and_launch(g, batch, b_is_kn, static_cast<hipStream_t>(stream));
+}
+
+// C = LayerNorm(R + act(A x B^T + bias)) (or act after the residual) over rows of exactly 256 columns, in ONE launch: the
+// Linear that ends a transformer sub-block with its residual add and LayerNorm (include/dfx_gemm.h)
+extern "C" int dfx_linear_ln_f32(const float *A, const float *A2, long lda, long a_block_stride, const float *W, long ldw,
+                                 const float *bias, const float *R, long ldr, const float *gamma, const float *beta,
+                                 float eps, float *C, long ldc, int M, int K, int act, int act_first, void *stream)
+{
+    const int N = 256;
+    if (M < 0 || K <= 0) return dfx::fail(DFX_EINVAL, "linear_ln: bad dimension");
+    if (act < 0 || act > 2) return dfx::fail(DFX_EINVAL, "linear_ln: activation code must be 0, 1 or 2");
+    if (M == 0) return DFX_OK;
+    if (!A || !W || !C || !gamma || !beta) return dfx::fail(DFX_EINVAL, "linear_ln: null pointer");
+    if ((K & 3) || (lda & 3) || (ldw & 3) || (ldc & 3) || (ldr & 3) || !dfx::aligned16(A) || !dfx::aligned16(W) || !dfx::aligned16(C) ||
+        (A2 && !dfx::aligned16(A2)) || (R && !dfx::aligned16(R)) || (bias && !dfx::aligned16(bias)) || !dfx::aligned16(gamma) ||
+        !dfx::aligned16(beta))
+        return dfx::fail(DFX_EINVAL, "linear_ln: K and the leading dimensions must be multiples of 4, buffers 16-byte aligned");
+    if (a_block_stride < 0 || (a_block_stride > 0 && (a_block_stride < (long)M * 4 || (a_block_stride & 3) || A2)))
+        return dfx::fail(DFX_EINVAL, "linear_ln: K-block-major A needs a_block_stride >= 4 * M (a multiple of 4) and no A2");
+    const long ea = a_block_stride > 0 ? (long)(K / 4) * a_block_stride : (long)M * lda;
+    if (ea * 4 >= (1L << 31) || (long)N * ldw * 4 >= (1L << 31) || (R && (long)M * ldr * 4 >= (1L << 31)))
+        return dfx::fail(DFX_ERANGE, "linear_ln: an operand exceeds 2 GiB");
+    Args g{A, A2, lda, 0, W, ldw, 0, bias, 0, R, ldr, 0, nullptr, 0, C, ldc, 0, M, N, K, act, 0, 0, a_block_stride, 1, 1, K};
+    g.ln_g = gamma;
+    g.ln_b = beta;
+    g.ln_eps = eps;
+    g.act_first = act_first;
+    return launch<64, 256, 1, 4>(g, 1, 0, static_cast<hipStream_t>(stream));
 }
 
 // Y[n] = act(W x [X1[n]; X2[n]] + bias): the last 1x1 convolution of a bottleneck and its stride-1 projection shortcut in

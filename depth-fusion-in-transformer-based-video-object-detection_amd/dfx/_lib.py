@@ -31,6 +31,7 @@ SIGNATURES = {
     # include/dfx_gemm.h
     "dfx_gemm_f32": [_p, _p, _l, _l, _p, _l, _l, _i, _p, _i, _p, _l, _l, _p, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "dfx_gemm_splitk_f32": [_p, _l, _p, _l, _i, _p, _i, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p, _p],
+    "dfx_linear_ln_f32": [_p, _p, _l, _l, _p, _l, _p, _p, _l, _p, _p, ctypes.c_float, _p, _l, _i, _i, _i, _i, _p],
     "dfx_conv1x1_pair_f32": [_p, _p, _l, _i, _p, _l, _i, _p, _p, _l, _i, _i, _i, _i, _p],
     # include/dfx_fused.h: x, bias, residual, out, N, C, HW, relu, stream
     "dfx_bias_act_nchw_f32": [_p, _p, _p, _p, _i, _i, _l, _i, _p],

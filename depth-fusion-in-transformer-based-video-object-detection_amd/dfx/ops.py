@@ -266,6 +266,7 @@ def _ptr(t):
 
 
 _GEMM_MAX_BYTES = 1 << 31          # tests lower it to exercise the row-range path on small tensors
+_FUSE_LN = os.environ.get("DFX_LINEAR_LN", "1") == "1"      # LayerNorm in the GEMM epilogue (dfx_linear_ln_f32); 0: separate pass
 
 
 def _split_k(M, N, K):
@@ -284,12 +285,16 @@ def _split_k(M, N, K):
 
 
 def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False,
-           act=None):
+           act=None, norm=None, act_first=False):
     """y = act((x (+ add)) @ weight.T + bias (+ residual)), rows where row_mask is True set to 0.
     act: None / "relu" / "gelu" (``relu=True`` is the older spelling of act="relu").
     The hand-written fp32 MFMA GEMM (include/dfx_gemm.h) standing in for nn.Linear with its
     neighbours fused: the ``src + pos`` query add, the bias, ReLU, the residual add and
     value_proj's masked_fill.  x [..., K] contiguous, weight [N, K] -> [..., N].
+
+    norm: an nn.LayerNorm(256) applied to the result rows in the same launch (include/dfx_gemm.h, dfx_linear_ln_f32):
+    y = norm(residual + act(...)) with ``act_first`` (the activation before the residual add), else norm(act(... + residual));
+    needs N == 256, no row_mask, no col_block.
 
     col_block = w > 0 stores the result column-block-major instead: [N / w, rows, w] (the layout
     msda_level_forward reads), N a multiple of w.  x_blocked: x is K-block-major [K/4, rows, 4] (the
@@ -326,6 +331,22 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         _require(row_mask.numel() == M, "row_mask must have one entry per row")
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
     code = ACT[act] if act is not None else int(bool(relu))
+    if norm is not None and not _FUSE_LN:       # A/B switch: the LayerNorm as its own pass
+        if code and not act_first:
+            y = linear(x, weight, bias, residual=residual, add=add, x_blocked=x_blocked, act=act, relu=relu)
+            return add_layernorm(y, None, norm)
+        y = linear(x, weight, bias, add=add, x_blocked=x_blocked, act=act, relu=relu)
+        return add_layernorm(y, None if residual is None else residual.reshape(y.shape), norm)
+    if norm is not None:
+        _require(N == 256 and row_mask is None and not col_block and norm.weight.numel() == 256 and norm.weight.is_cuda,
+                 "linear(norm=...): a LayerNorm over exactly 256 output columns, no row_mask / col_block")
+        _require(M * K * 4 < _GEMM_MAX_BYTES, "linear(norm=...): operand of 2 GiB or more")
+        with torch.cuda.device(x.device):
+            rc = lib.dfx_linear_ln_f32(x2.data_ptr(), _ptr(add), K, M * 4 if x_blocked else 0, weight.data_ptr(), K, _ptr(bias),
+                                       _ptr(residual), N, norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
+                                       out.data_ptr(), N, M, K, code, int(bool(act_first)), _stream(x.device))
+        _lib.check(rc, "linear + LayerNorm")
+        return out
     splits = _split_k(M, N, K) if (add is None and row_mask is None and not col_block and not x_blocked and N % 4 == 0) else 0
     with torch.cuda.device(x.device):
         if splits > 1:

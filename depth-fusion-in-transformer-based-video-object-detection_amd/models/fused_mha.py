@@ -21,9 +21,10 @@ def usable(mha, *tensors):
             and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
 
 
-def forward(mha, q_in, k_in, v_in):
+def forward(mha, q_in, k_in, v_in, post=None):
     """mha: nn.MultiheadAttention; q_in [B,Lq,E], k_in / v_in [B,Lk,E] -> [B,Lq,E]
-    (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights)."""
+    (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights).
+    post = (residual [B,Lq,E], norm): -> norm(residual + output), the add and the LayerNorm in out_proj's GEMM epilogue."""
     E, H = mha.embed_dim, mha.num_heads
     W, b = mha.in_proj_weight, mha.in_proj_bias
     B, Lq, _ = q_in.shape
@@ -42,4 +43,7 @@ def forward(mha, q_in, k_in, v_in):
         k = _ops.linear(k_in, W[E:2 * E], b[E:2 * E]).view(B, Lk, E)
         v = _ops.linear(v_in, W[2 * E:], b[2 * E:]).view(B, Lk, E)
     ctx = _ops.mha(q, k, v, H, 1.0 / math.sqrt(E // H))
-    return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
+    if post is not None and E == 256:
+        return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias, residual=post[0].contiguous(), norm=post[1])
+    out = _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
+    return out if post is None else post[1](post[0] + out)

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from models.fused import Linear
-from models.transformer_layers import _norm_add
+from models.transformer_layers import _linear_norm_add, _norm_add
 
 _DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
 
@@ -86,17 +86,17 @@ class RCNNHead(nn.Module):
         q = pro_features.view(N, nr_boxes, self.d_model).permute(1, 0, 2)                 # nr,N,C
         from .. import fused_mha
         if fused_mha.usable(self.self_attn, pro_features):
+            # batch-first all the way: residual + LayerNorm ride in out_proj's GEMM epilogue
             pf = pro_features.reshape(N, nr_boxes, self.d_model)
-            attn = fused_mha.forward(self.self_attn, pf, pf, pf).permute(1, 0, 2)           # nr,N,C
+            q = fused_mha.forward(self.self_attn, pf, pf, pf, post=(pf, self.norm1)).reshape(1, N * nr_boxes, self.d_model)
         else:
             attn = self.self_attn(q, q, value=q)[0]
-        q = _norm_add(self.norm1, q, self.dropout1(attn))      # residual + LayerNorm in one pass on the GPU
-        q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
+            q = _norm_add(self.norm1, q, self.dropout1(attn))
+            q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
         obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi)).view_as(q))
         if (self.activation is F.relu and obj.is_cuda and obj.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue
             hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
         else:
             hdn = self.activation(self.linear1(obj))
-        y = self.linear2(self.dropout(hdn))
-        return _norm_add(self.norm3, obj, self.dropout3(y))
+        return _linear_norm_add(self.linear2, self.dropout(hdn), self.norm3, obj)

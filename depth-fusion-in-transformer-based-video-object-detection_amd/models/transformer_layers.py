@@ -49,13 +49,38 @@ def _linear_act(linear, activation, x):
     return activation(linear(x))
 
 
-def _mha(module, q, k, v):
+def _mha(module, q, k, v, post=None):
     """nn.MultiheadAttention on batch-first [B,L,E] tensors (no masks, attention weights unused): the fused
-    GEMM + attention-kernel route in GPU inference (models/fused_mha.py), the module itself otherwise."""
+    GEMM + attention-kernel route in GPU inference (models/fused_mha.py), the module itself otherwise.
+    post = (residual, norm): -> norm(residual + attention output) (in out_proj's GEMM epilogue on the fused route)."""
     from . import fused_mha
     if fused_mha.usable(module, q, k, v):
-        return fused_mha.forward(module, q, k, v)
-    return module(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1))[0].transpose(0, 1)
+        return fused_mha.forward(module, q, k, v, post)
+    out = module(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1))[0].transpose(0, 1)
+    return out if post is None else post[1](post[0] + out)
+
+
+def _gpu_inference(x):
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+def _linear_norm_add(linear, x, norm, residual=None, act=None, act_first=False):
+    """norm(residual + act(linear(x))) (act_first) or norm(act(linear(x) + residual)); one MFMA GEMM launch with the
+    residual add and the LayerNorm in its epilogue in GPU inference when the Linear ends in d_model = 256 columns
+    (dfx.ops.linear(norm=...)), the separate ops otherwise."""
+    if _gpu_inference(x) and linear.out_features == 256 and linear.in_features % 4 == 0 and linear.weight.dtype == torch.float32:
+        from dfx import ops as _ops
+        return _ops.linear(x.contiguous(), linear.weight, linear.bias, act=act, residual=None if residual is None else residual.contiguous(),
+                           norm=norm, act_first=act_first)
+    y = linear(x)
+    fn = {None: None, "relu": F.relu, "gelu": F.gelu}[act]
+    if fn is not None and act_first:
+        y = fn(y)
+    if residual is not None:
+        y = residual + y
+    if fn is not None and not act_first:
+        y = fn(y)
+    return norm(y)
 
 
 def _norm_add(norm, x, y=None):
@@ -157,12 +182,16 @@ class DeformableTransformerEncoderLayer(nn.Module):
             query = (src, pos)                     # the add rides along into the projection GEMM
         else:
             query = _add_pos(src, pos)
-        y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        src = _norm_add(self.norm1, src, self.dropout1(y))
-        if fused and self.activation is F.relu and src.shape[0] * src.shape[1] >= 2048:
-            from dfx import ops as _ops            # linear1 + bias + ReLU in one MFMA GEMM
+        if fused:       # residual add + LayerNorm in output_proj's epilogue
+            src = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
+                                 post=(src, self.norm1))
+        else:
+            y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+            src = _norm_add(self.norm1, src, self.dropout1(y))
+        if fused and self.activation is F.relu:
+            from dfx import ops as _ops            # linear1 + bias + ReLU in one MFMA GEMM, linear2 + residual + LayerNorm in another
             h = _ops.linear(src.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
-            return _norm_add(self.norm2, src, self.linear2(h))
+            return _linear_norm_add(self.linear2, h, self.norm2, src)
         return self.forward_ffn(src)
 
 
@@ -212,17 +241,17 @@ class _CrossFusionBlock(nn.Module):
     def forward_ffn(self, tgt):
         if (self.activation is F.gelu and tgt.is_cuda and tgt.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # Linear + bias + exact GELU in one MFMA GEMM
-            y = _ops.linear(tgt.contiguous(), self.linear1.weight, self.linear1.bias, act="gelu")
-        else:
-            y = self.activation(self.linear1(tgt))
+            # Linear + bias + exact GELU + residual + LayerNorm in one MFMA GEMM
+            return _linear_norm_add(self.linear1, tgt, getattr(self, self._ffn_norm), tgt, act="gelu", act_first=True)
+        y = self.activation(self.linear1(tgt))
         return _norm_add(getattr(self, self._ffn_norm), tgt, getattr(self, self._ffn_drop)(y))
 
     def _fuse(self, tgt, query_pos, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask):
-        src = _norm_add(self.norm_depth_scale, self.depth_scale_adapt(src))
+        src = _linear_norm_add(self.depth_scale_adapt, src, self.norm_depth_scale)
         fused = tgt.is_cuda and not torch.is_grad_enabled() and tgt.dtype == torch.float32 and query_pos is not None
         query = (tgt, query_pos) if fused else _add_pos(tgt, query_pos)
         y = self.cross_attn(query, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask)
-        tgt = _norm_add(self.norm1, tgt, self.dropout1(self.cross_scale_adapt(y)))
+        tgt = _linear_norm_add(self.cross_scale_adapt, y, self.norm1, tgt)
         return self.forward_ffn(tgt)
 
 
@@ -310,17 +339,14 @@ class DeformableTransformerDecoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
-        return _norm_add(self.norm3, tgt, self.dropout4(y))
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        y = _mha(self.self_attn, qk, qk, tgt)
-        tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
-        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                            level_start_index, src_padding_mask)
-        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
+        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2))
+        tgt = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                              level_start_index, src_padding_mask, post=(tgt, self.norm1))
         return self.forward_ffn(tgt)
 
 
@@ -410,15 +436,13 @@ class TemporalQueryEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
-        return _norm_add(self.norm3, tgt, self.dropout4(y))
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
 
     def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
         qk = _add_pos(query, query_pos)
-        y = _mha(self.self_attn, qk, qk, query)
-        tgt = _norm_add(self.norm2, query, self.dropout2(y))
-        y = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query)
-        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
+        tgt = _mha(self.self_attn, qk, qk, query, post=(query, self.norm2))
+        tgt = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query,
+                   post=(tgt, self.norm1))
         return self.forward_ffn(tgt)
 
 
@@ -458,15 +482,12 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        y = self.linear2(self.dropout3(_linear_act(self.linear1, self.activation, tgt)))
-        return _norm_add(self.norm3, tgt, self.dropout4(y))
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        y = _mha(self.self_attn, qk, qk, tgt)
-        tgt = _norm_add(self.norm2, tgt, self.dropout2(y))
-        y = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                            frame_start_index, src_padding_mask)
-        tgt = _norm_add(self.norm1, tgt, self.dropout1(y))
+        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2))
+        tgt = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                              frame_start_index, src_padding_mask, post=(tgt, self.norm1))
         return self.forward_ffn(tgt)

@@ -45,6 +45,14 @@
  * with W = [W3 | Wd] (frozen-BN scales folded in, bias = shift3 + shiftd): the shortcut map is neither written nor
  * read back as a residual.  X1 [batch,K1,HW], X2 [batch,K2,HW] (image strides in floats), W [Co,K1+K2] row-major,
  * Y [batch,Co,HW]; K1, K2 multiples of 16, HW of 4.
+ *
+ * dfx_linear_ln_f32: C = LayerNorm(R + act((A (+ A2)) x W^T + bias)) over rows of exactly 256 columns (d_model) in ONE
+ * launch - the Linear that ends a transformer sub-block with the residual add and the LayerNorm that follow it
+ * (output_proj / linear2 + dropout(identity) + norm: /root/reference/models/deformable_transformer_single.py:544-560,
+ * 379-402, 596-648).  A workgroup owns whole rows (64 x 256 tile), so the row statistics are wave reductions in the
+ * epilogue: mean, then the centred second moment (two passes over registers), eps inside the square root, gamma / beta.
+ * act_first = 1 applies the activation before the residual is added (the fusion blocks' LN(t + GELU(Linear(t)))), 0 after.
+ * A [M,K] row-major (lda) or K-block-major (a_block_stride > 0, as dfx_gemm_f32), W [256,K] row-major (ldw), R / C [M,256].
  */
 #ifndef DFX_GEMM_H
 #define DFX_GEMM_H
@@ -66,6 +74,10 @@ int dfx_gemm_splitk_f32(const float *A, long lda, const float *B, long ldb, int 
                         const float *bias, int bias_per_row, const float *R, long ldr,
                         float *C, long ldc, int M, int N, int K, int act, int splits,
                         float *workspace, void *stream);
+
+int dfx_linear_ln_f32(const float *A, const float *A2, long lda, long a_block_stride, const float *W, long ldw,
+                      const float *bias, const float *R, long ldr, const float *gamma, const float *beta, float eps,
+                      float *C, long ldc, int M, int K, int act, int act_first, void *stream);
 
 int dfx_conv1x1_pair_f32(const float *W, const float *X1, long strideX1, int K1,
                          const float *X2, long strideX2, int K2, const float *bias,

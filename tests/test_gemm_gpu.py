@@ -366,3 +366,43 @@ def test_conv1x1_pair_matches_fp64(K1, K2, Co, H, W, N):
     assert (got.double() - want).abs().max().item() < 4e-6 * (K1 + K2) ** 0.5
     assert torch.equal(ops.conv1x1_pair(x1, x2, w, None, relu=False) + b.view(1, -1, 1, 1),
                        ops.conv1x1(torch.cat([x1, x2], 1), w, None) + b.view(1, -1, 1, 1))
+
+
+@pytest.mark.parametrize("M,K,act,act_first,res,add,blocked", [
+    (4200, 256, None, False, True, False, False), (4200, 1024, None, False, True, False, False),
+    (1200, 256, "gelu", True, True, False, False), (333, 256, None, False, False, False, False),
+    (8400, 256, None, False, True, False, True), (300, 2048, None, False, True, False, False),
+    (130, 64, "relu", False, True, True, False)])
+def test_linear_with_layernorm_epilogue_matches_fp64(M, K, act, act_first, res, add, blocked):
+    """LayerNorm(residual + act(x W^T + b)) in ONE launch (dfx_linear_ln_f32: 64 x 256 tile, row statistics by wave
+    reductions in the epilogue) against the float64 formulation, incl. the activation-before-residual order of the fusion
+    blocks, no residual, the K-block-major A operand the level kernel writes, the ``add`` prologue."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(256, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    r = torch.randn(M, 256, generator=g).cuda() if res else None
+    a = torch.randn(M, K, generator=g).cuda() if add else None
+    norm = torch.nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(256, generator=g) * 0.2 + 1)
+        norm.bias.copy_(torch.randn(256, generator=g) * 0.2)
+    xin = x.view(M, K // 4, 4).permute(1, 0, 2).contiguous() if blocked else x
+    got = ops.linear(xin, w, b, act=act, residual=r, add=a, norm=norm, act_first=act_first, x_blocked=blocked)
+    y = (x.double() + (0 if a is None else a.double())) @ w.double().t() + b.double()
+    fn = {None: lambda t: t, "relu": torch.relu, "gelu": torch.nn.functional.gelu}[act]
+    if act_first:
+        y = fn(y)
+    if r is not None:
+        y = y + r.double()
+    if not act_first:
+        y = fn(y)
+    want = torch.nn.functional.layer_norm(y, (256,), norm.weight.double(), norm.bias.double(), norm.eps)
+    assert got.shape == (M, 256)
+    assert (got.double() - want).abs().max().item() < 2e-5
+    # and the same bits as the two-launch formulation up to rounding of the statistics
+    sep = ops.add_layernorm(ops.linear(xin, w, b, act=act if act_first else None, add=a, x_blocked=blocked) if (act_first or act is None)
+                            else ops.linear(xin, w, b, act=act, residual=r, add=a, x_blocked=blocked),
+                            r if (act_first or act is None) else None, norm)
+    assert (got - sep).abs().max().item() < 2e-5
