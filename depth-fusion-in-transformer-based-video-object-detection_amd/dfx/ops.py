@@ -266,7 +266,13 @@ def _ptr(t):
 
 
 _GEMM_MAX_BYTES = 1 << 31          # tests lower it to exercise the row-range path on small tensors
-_FUSE_LN = os.environ.get("DFX_LINEAR_LN", "1") == "1"      # LayerNorm in the GEMM epilogue (dfx_linear_ln_f32); 0: separate pass
+# LayerNorm in the GEMM epilogue (dfx_linear_ln_f32) - OFF: measured slower than GEMM + add_layernorm on this chip (round 3,
+# profiles/r03_linear_ln.txt: the 64 x 256 tile that owns whole rows runs its K loop with 36 % more LDS-DMA pieces per MFMA than
+# the 128 x 128 tile and leaves 19 workgroups for the 1200-row Linears of a 4-frame block: spatial stage 16.80 -> 16.97 ms with
+# it on the 134 400-row Linears only, 16.7 -> 17.3 ms on all of them, the 4-frame rank step 16.65 -> 18.9 ms).  DFX_LINEAR_LN=1
+# turns it on for A/B runs; the callers' ``norm=`` plumbing then costs nothing when it is off.
+_FUSE_LN = os.environ.get("DFX_LINEAR_LN", "0") == "1"
+_FUSE_LN_MIN_ROWS = int(os.environ.get("DFX_LINEAR_LN_MIN_ROWS", "32768"))
 
 
 def _split_k(M, N, K):
@@ -331,7 +337,7 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         _require(row_mask.numel() == M, "row_mask must have one entry per row")
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
     code = ACT[act] if act is not None else int(bool(relu))
-    if norm is not None and not _FUSE_LN:       # A/B switch: the LayerNorm as its own pass
+    if norm is not None and (not _FUSE_LN or M < _FUSE_LN_MIN_ROWS):       # the LayerNorm as its own pass
         if code and not act_first:
             y = linear(x, weight, bias, residual=residual, add=add, x_blocked=x_blocked, act=act, relu=relu)
             return add_layernorm(y, None, norm)

@@ -373,11 +373,13 @@ def test_conv1x1_pair_matches_fp64(K1, K2, Co, H, W, N):
     (1200, 256, "gelu", True, True, False, False), (333, 256, None, False, False, False, False),
     (8400, 256, None, False, True, False, True), (300, 2048, None, False, True, False, False),
     (130, 64, "relu", False, True, True, False)])
-def test_linear_with_layernorm_epilogue_matches_fp64(M, K, act, act_first, res, add, blocked):
+def test_linear_with_layernorm_epilogue_matches_fp64(M, K, act, act_first, res, add, blocked, monkeypatch):
     """LayerNorm(residual + act(x W^T + b)) in ONE launch (dfx_linear_ln_f32: 64 x 256 tile, row statistics by wave
     reductions in the epilogue) against the float64 formulation, incl. the activation-before-residual order of the fusion
     blocks, no residual, the K-block-major A operand the level kernel writes, the ``add`` prologue."""
     from dfx import ops
+    monkeypatch.setattr(ops, "_FUSE_LN", True)              # (off by default: slower than two launches, see dfx/ops.py)
+    monkeypatch.setattr(ops, "_FUSE_LN_MIN_ROWS", 0)
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn(M, K, generator=g).cuda()
     w = (torch.randn(256, K, generator=g) / K ** 0.5).cuda()
