@@ -63,9 +63,9 @@ torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
 
 # HBM-side traffic of one MSDA encoder-geometry launch, per frame, from the PMC passes committed in
-# profiles/r01_pmc_msda_level_N8.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 8 frames, the
+# profiles/r03_pmc_msda_level.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 32 frames, the
 # factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
-MSDA_TRAFFIC_PER_FRAME = (2 * 24211.8 + 33600.0) * 1024 / 8
+MSDA_TRAFFIC_PER_FRAME = (2 * 96670.5 + 134400.0) * 1024 / 32
 # fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
 # family's launches per step, from the PMC passes over this workload committed in profiles/r03_pmc_traffic.md
 FAMILY_TRAFFIC_PER_STEP = {"gemm": (101183.9e6, 210), "wino": (18905.2e6, 28), "igemm": (33025.4e6, 9)}
@@ -427,7 +427,7 @@ def main():
                     "bound": "hbm", "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
                     "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, rank_frames)),
-                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_msda_level_N8.md",
+                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r03_pmc_msda_level.md",
                     "launches_per_step": round(len(enc) / steps_profiled, 1), "bytes_per_launch": nbytes,
                     "avg_launch_us": round(mean_t * 1e6, 2),
                     "share_of_step": round(mean_t * len(enc) / steps_profiled / step_s, 4)}
