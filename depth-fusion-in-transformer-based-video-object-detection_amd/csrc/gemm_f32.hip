@@ -624,6 +624,11 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
         const bool rows_fit = (M % 128 == 0) || M >= 1024;
         // split-K launches are sized by the caller to fill one resident round of 128 x 128 tiles (3 per CU)
         if (g.splits > 1 && M >= 128 && N >= 128 && t128x128 <= 768) return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
+        // 8 waves on a 256 x 128 tile (two workgroups = 4 waves per SIMD, a quarter fewer LDS-DMA pieces per MFMA): 2-3 % ahead of
+        // 128 x 128 on the 2048-channel convolutions of layer4 and behind it everywhere else (profiles/r03_gemm_tile256.txt:
+        // ffn2 +10 %, layer3 +9-11 %, layer4 conv1 +4 %, the short-K shapes far worse)
+        if (b_is_kn && M % 256 == 0 && M >= 2048 && K >= 512 && t128x128 >= 2048 && g.splits <= 1)
+            return launch<256, 128, 4, 2>(g, batch, b_is_kn, st);
         if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 512)))
             return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     }
