@@ -79,3 +79,22 @@ for F_, mb, ov in eval(CASES) if CASES else [(32, 8, False), (32, 8, True), (16,
     dt = (time.perf_counter() - t0) / n
     print(f"frames/rank {F_:2d} (N={T // F_} GPUs)  micro-batch {mb}  overlap {int(ov)}: {dt * 1e3:7.2f} ms/step "
           f"-> {T / dt:7.1f} frames/s whole job", flush=True)
+
+# clips as a stream at the rank's block size (ClipRunner.submit: the tail of step k on a second HIP stream beside the backbones
+# of step k + 1) - what `bench.py --pipeline 2` does for N > 1; the exchange is stood in by repeating the rank's own query sets
+if os.environ.get("PIPE", "0") == "1":
+    for F_ in (4, 8, 16):
+        x = clip[:F_].to(dev)
+        runner = ClipRunner(model, micro_batch=F_, overlap=False)
+        rep = T // F_
+        runner.exchange = lambda ref, logits, clips=1, rep=rep: (ref.repeat(rep, 1, 1), logits.repeat(rep, 1, 1))
+        for _ in range(3):
+            runner.submit(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 8
+        for _ in range(n):
+            runner.submit(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"pipelined: frames/rank {F_:2d} (N={T // F_} GPUs): {dt * 1e3:7.2f} ms/step -> {T / dt:7.1f} frames/s whole job", flush=True)
