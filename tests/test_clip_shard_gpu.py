@@ -189,3 +189,39 @@ def test_clip_outputs_are_run_to_run_deterministic():
                 assert torch.equal(a, b)
     finally:
         torch.backends.cudnn.deterministic = saved
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DFX_PKG"]); sys.path.insert(0, os.environ["DFX_ROOT"])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["DFX_PORT"], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+from tests.test_clip_shard_gpu import _build, _clip
+from models.clip_inference import ClipRunner
+model = _build()
+clip = _clip().cuda()
+want = ClipRunner(model, micro_batch=4)(clip)                       # no process group: no exchange
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL
+runner = ClipRunner(model, micro_batch=4)
+runner.gather_on_one_rank = True                                     # run the collective although world == 1
+got = runner(clip)                                                   # all_gather_into_tensor on the current stream
+outs = [runner.submit(clip) for _ in range(3)]                       # ... and on the side stream of the clip pipeline
+torch.cuda.synchronize()
+dist.barrier()
+for o in [got] + [o for o, _ in outs]:
+    for k in ("pred_logits", "pred_boxes"):
+        assert torch.equal(o[k], want[k]), k
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+@pytest.mark.timeout(600)
+def test_rccl_call_path_with_one_rank():
+    """The exchange through RCCL itself (backend "nccl") with ONE rank - all this box allows: process-group initialisation on
+    the device, `all_gather_into_tensor` of the packed query sets on the current stream and on the side stream of the clip
+    pipeline (`ClipRunner.submit`), a barrier, bit-equal outputs.  What it cannot show is the transport between GPUs."""
+    import subprocess
+    env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(29300 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=550, env=env)
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
