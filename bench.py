@@ -246,10 +246,11 @@ def main():
                     help="two-stream schedule inside a rank: backbones of micro-batch i+1 beside the transformer "
                          "tail of micro-batch i (ClipRunner; same results)")
     ap.add_argument("--pipeline", type=int, default=1,
-                    help="clips are a stream: queue each step with ClipRunner.submit, so the transformer tail of clip k "
-                         "runs on a second HIP stream beside the backbones of clip k+1 (same results, +5 %% frames/s; 0 = one "
-                         "clip at a time on one stream; 1 = on for a single GPU - the default; the per-kernel roofline "
-                         "durations then come from one extra single-stream step; 2 = on for N > 1 as well)")
+                    help="clips are a stream: queue each step with ClipRunner.submit, so the transformer tail of clip k - and "
+                         "for N > 1 the exchange - runs on a second HIP stream beside the backbones of clip k+1 (same results; "
+                         "+4 %% frames/s at 32 frames per GPU, +13 %% at 4; 0 = one clip at a time on one stream; 1 = on, the "
+                         "default for every N since round 3: the per-kernel roofline durations then come from one extra "
+                         "single-stream step)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
@@ -296,9 +297,9 @@ def main():
     runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap))
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
-    # N > 1: the exchange would sit on the side stream; that is how torch.distributed's NCCL backend is meant to be
-    # used, but it could not be exercised on RCCL in this round (one GPU per session), so it needs --pipeline 2
-    pipelined = n_micro == 1 and (a.pipeline >= 2 or (a.pipeline == 1 and world == 1))
+    # N > 1: the exchange sits on the side stream - how torch.distributed's NCCL backend is meant to be used; exercised on
+    # RCCL with one rank (tests/test_clip_shard_gpu.py::test_rccl_call_path_with_one_rank) and with two ranks over gloo
+    pipelined = n_micro == 1 and a.pipeline >= 1
     step = (lambda: runner.submit(mine, clips=clips)) if pipelined else (lambda: runner(mine, clips=clips))
 
     def barrier():
