@@ -60,6 +60,7 @@ struct WinoArgs {
     int nchunk, ntb;     // Ci / 8, tile blocks
     unsigned xbytes, ubytes;
     int lb0;             // first logical block of this launch
+    int no_phase;        // A/B switch: every wave loads before and transforms after its MFMAs (no phase shift between SIMD partners)
 };
 
 __device__ __forceinline__ float activate(float v, int act)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     // after them; waves 4-7 ("late") transform / store chunk t+1 - loaded one iteration earlier - BEFORE their MFMAs of
     // chunk t, then load chunk t+2.  Either way chunk t+1 is complete at the barrier that ends iteration t, and the
     // buffer it goes to (that of chunk t-1) was released by the previous barrier.
-    const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    const bool late = !g.no_phase && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
 #ifdef DFX_WINO_STAMP
     unsigned long long *stamp_base = nullptr;
     if (CB == 2 && g_wino_stamps && (wave == 0 || wave == 4) && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 8)
@@ -433,6 +434,10 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     g.strideX = (long)Ci * H * W;
     g.strideY = (long)Co * H * W;
     g.nchunk = Ci / kCK;
+    // the phase shift between SIMD partners pays with many chunks (layer3 / layer4: 1.5 % faster with it, A/B of round 3);
+    // with 8 chunks (layer1, Ci = 64) the kernel is 1.4 % faster without it
+    static const char *np_env = getenv("DFX_WINO_NO_PHASE");
+    g.no_phase = np_env ? np_env[0] == '1' : g.nchunk <= 8;
     g.xbytes = (unsigned)((long)N * Ci * H * W * 4);
     g.ubytes = (unsigned)((long)16 * Co * Ci * 4);
     const long ntb = (g.tiles + kTB - 1) / kTB;
