@@ -436,6 +436,7 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     g.nchunk = Ci / kCK;
     // the phase shift between SIMD partners pays with many chunks (layer3 / layer4: 1.5 % faster with it, A/B of round 3);
     // with 8 chunks (layer1, Ci = 64) the kernel is 1.4 % faster without it
+    // (s_setprio 1 for waves 4-7, the static-priority recipe of the bf16 attention loops: 4-5 % SLOWER here, round 3)
     static const char *np_env = getenv("DFX_WINO_NO_PHASE");
     g.no_phase = np_env ? np_env[0] == '1' : g.nchunk <= 8;
     g.xbytes = (unsigned)((long)N * Ci * H * W * 4);
