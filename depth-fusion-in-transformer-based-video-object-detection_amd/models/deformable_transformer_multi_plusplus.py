@@ -109,10 +109,15 @@ class DeformableTransformer(SpatialTransformerBase):
         out = dict(logits=logits, boxes=boxes)
         roi = self.temporal_roi_layers1[0]
         head = self.dynamic_layer_for_current_query1
+        pooled = []
         for role in roles:
             mem = memory if role == "cur" else memory + pos_embed
             fmap = mem.permute(0, 2, 1).unsqueeze(-1).view(F_, C, h, w)           # channels-last view, no copy
-            out[role] = head(roi(fmap, rois), hs_last).view(F_, Q, C)
+            pooled.append(roi(fmap, rois))
+        # both roles share the head's query self-attention and its dynamic_layer (they see hs_last only): one pass
+        fused = head(pooled, hs_last) if len(pooled) > 1 else [head(pooled[0], hs_last)]
+        for role, y in zip(roles, fused):
+            out[role] = y.view(F_, Q, C)
         return out
 
     def temporal_stage(self, cur_hs, cur_reference_out, cur_memory, ref_pool, logit_pool, others,

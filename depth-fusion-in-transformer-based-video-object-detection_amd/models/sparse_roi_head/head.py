@@ -39,19 +39,22 @@ class DynamicConv(nn.Module):
         self.out_layer = Linear(self.hidden_dim * res ** 2, self.hidden_dim)
         self.norm3 = nn.LayerNorm(self.hidden_dim)
 
-    def forward(self, pro_features, roi_features):
-        """pro_features (1, K, C); roi_features (49, K, C) -> (K, C)."""
+    def forward(self, pro_features, roi_features, params=None):
+        """pro_features (1, K, C); roi_features (49, K, C) -> (K, C).  ``params``: the output of ``dynamic_layer(pro_features)``
+        when the caller already has it (it depends on the queries only: RCNNHead shares it between RoI feature sets)."""
         feats = roi_features.permute(1, 0, 2)                               # K,49,C
+        if params is None:
+            params = self.dynamic_layer(pro_features)
         if (feats.is_cuda and feats.dtype == torch.float32 and not torch.is_grad_enabled() and feats.is_contiguous()
                 and self.hidden_dim == 256 and self.dim_dynamic == 64 and feats.shape[1] <= 64
                 and isinstance(self.activation, nn.ReLU)):
             # both per-RoI products and their LayerNorm + ReLU in one launch (csrc/dynconv.hip)
             from dfx import ops as _ops
-            params2 = self.dynamic_layer(pro_features).view(feats.shape[0], -1)            # K, 2*C*dd
+            params2 = params.view(feats.shape[0], -1)                                       # K, 2*C*dd
             feats = _ops.dynamic_conv(feats, params2, self.norm1, self.norm2)
             feats = self.out_layer(feats.flatten(1))
             return self.activation(_norm_add(self.norm3, feats))
-        params = self.dynamic_layer(pro_features).permute(1, 0, 2)          # K,1,2*C*dd
+        params = params.permute(1, 0, 2)                                    # K,1,2*C*dd
         k1 = params[:, :, : self.num_params].reshape(-1, self.hidden_dim, self.dim_dynamic)
         k2 = params[:, :, self.num_params:].reshape(-1, self.dim_dynamic, self.hidden_dim)
         feats = self.activation(self.norm1(torch.bmm(feats, k1)))
@@ -80,9 +83,18 @@ class RCNNHead(nn.Module):
         self.scale_clamp, self.bbox_weights = scale_clamp, bbox_weights
 
     def forward(self, roi_features, pro_features):
-        """roi_features (N*nr_boxes, C, 7, 7); pro_features (N, nr_boxes, C) -> (1, N*nr_boxes, C)."""
+        """roi_features (N*nr_boxes, C, 7, 7); pro_features (N, nr_boxes, C) -> (1, N*nr_boxes, C).
+        A list / tuple of RoI feature tensors (the same boxes pooled from several maps: TransVOD++ pools every frame's boxes
+        from its plain memory and from memory + positions) gives a list of outputs; the self-attention over the queries and the
+        32768-wide ``dynamic_layer`` - which see the queries only - then run once instead of once per feature set."""
+        if isinstance(roi_features, (list, tuple)):
+            q = self._queries(pro_features)
+            params = self.inst_interact.dynamic_layer(q)
+            return [self._interact(q, r, pro_features, params) for r in roi_features]
+        return self._interact(self._queries(pro_features), roi_features, pro_features)
+
+    def _queries(self, pro_features):
         N, nr_boxes = pro_features.shape[:2]
-        roi = roi_features.view(N * nr_boxes, self.d_model, -1).permute(2, 0, 1)          # 49,K,C
         q = pro_features.view(N, nr_boxes, self.d_model).permute(1, 0, 2)                 # nr,N,C
         from .. import fused_mha
         if fused_mha.usable(self.self_attn, pro_features):
@@ -93,7 +105,12 @@ class RCNNHead(nn.Module):
             attn = self.self_attn(q, q, value=q)[0]
             q = _norm_add(self.norm1, q, self.dropout1(attn))
             q = q.view(nr_boxes, N, self.d_model).permute(1, 0, 2).reshape(1, N * nr_boxes, self.d_model)
-        obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi)).view_as(q))
+        return q
+
+    def _interact(self, q, roi_features, pro_features, params=None):
+        N, nr_boxes = pro_features.shape[:2]
+        roi = roi_features.view(N * nr_boxes, self.d_model, -1).permute(2, 0, 1)          # 49,K,C
+        obj = _norm_add(self.norm2, q, self.dropout2(self.inst_interact(q, roi, params)).view_as(q))
         if (self.activation is F.relu and obj.is_cuda and obj.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # bias + ReLU in the GEMM epilogue
             hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
