@@ -21,14 +21,30 @@ def usable(mha, *tensors):
             and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
 
 
-def forward(mha, q_in, k_in, v_in, post=None):
+def project_kv(mha, pool):
+    """K and V projections of a POOL of key / value rows [rows, E] in one GEMM -> [rows, 2E] ([K | V]); rows gathered from it
+    are the projections of the gathered rows (a Linear is row-wise), so a pool shared by many queries' key sets is projected once."""
+    E = mha.embed_dim
+    return _ops.linear(pool.contiguous(), mha.in_proj_weight[E:], mha.in_proj_bias[E:])
+
+
+def forward(mha, q_in, k_in, v_in, post=None, kv=None):
     """mha: nn.MultiheadAttention; q_in [B,Lq,E], k_in / v_in [B,Lk,E] -> [B,Lq,E]
     (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights).
-    post = (residual [B,Lq,E], norm): -> norm(residual + output), the add and the LayerNorm in out_proj's GEMM epilogue."""
+    post = (residual [B,Lq,E], norm): -> norm(residual + output), the add and the LayerNorm in out_proj's GEMM epilogue.
+    kv [B,Lk,2E]: already projected keys / values (``project_kv`` rows); k_in / v_in are then ignored."""
     E, H = mha.embed_dim, mha.num_heads
     W, b = mha.in_proj_weight, mha.in_proj_bias
     B, Lq, _ = q_in.shape
     Lk = k_in.shape[1]
+    if kv is not None:
+        Lk = kv.shape[1]
+        q = _ops.linear(q_in.contiguous(), W[:E], b[:E]).view(B, Lq, E)
+        ctx = _ops.mha(q, kv[..., :E], kv[..., E:], H, 1.0 / math.sqrt(E // H))
+        if post is not None and E == 256:
+            return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias, residual=post[0].contiguous(), norm=post[1])
+        out = _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
+        return out if post is None else post[1](post[0] + out)
     same_qk, same_kv = q_in is k_in, k_in is v_in
     q_in, k_in, v_in = q_in.contiguous(), k_in.contiguous(), v_in.contiguous()
     if same_qk and same_kv:                                 # one projection for q, k, v

@@ -438,12 +438,26 @@ class TemporalQueryEncoderLayer(nn.Module):
     def forward_ffn(self, tgt):
         return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
 
-    def forward(self, query, ref_query, query_pos=None, ref_query_pos=None):
+    def forward(self, query, ref_query, query_pos=None, ref_query_pos=None, ref_kv=None):
+        """ref_kv [B,Lk,2E]: the cross-attention's key / value projections of ``ref_query``, when the caller gathered them from
+        a pool it projected once (``project_ref_pool``; GPU inference route); ``ref_query`` is then not read."""
         qk = _add_pos(query, query_pos)
         tgt = _mha(self.self_attn, qk, qk, query, post=(query, self.norm2))
-        tgt = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query,
-                   post=(tgt, self.norm1))
+        if ref_kv is not None:
+            from . import fused_mha
+            tgt = fused_mha.forward(self.cross_attn, _add_pos(tgt, query_pos), None, None, post=(tgt, self.norm1), kv=ref_kv)
+        else:
+            tgt = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query,
+                       post=(tgt, self.norm1))
         return self.forward_ffn(tgt)
+
+    def project_ref_pool(self, pool):
+        """[rows, E] reference queries -> [rows, 2E] their key / value projections for ``forward(ref_kv=...)``, or None when
+        the fused GPU route does not apply (the caller then hands the gathered queries over as before)."""
+        from . import fused_mha
+        if fused_mha.usable(self.cross_attn, pool):
+            return fused_mha.project_kv(self.cross_attn, pool)
+        return None
 
 
 class TemporalQueryEncoder(nn.Module):
