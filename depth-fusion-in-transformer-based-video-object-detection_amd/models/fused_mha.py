@@ -36,15 +36,14 @@ def forward(mha, q_in, k_in, v_in, post=None, kv=None):
     E, H = mha.embed_dim, mha.num_heads
     W, b = mha.in_proj_weight, mha.in_proj_bias
     B, Lq, _ = q_in.shape
-    Lk = k_in.shape[1]
     if kv is not None:
-        Lk = kv.shape[1]
         q = _ops.linear(q_in.contiguous(), W[:E], b[:E]).view(B, Lq, E)
         ctx = _ops.mha(q, kv[..., :E], kv[..., E:], H, 1.0 / math.sqrt(E // H))
         if post is not None and E == 256:
             return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias, residual=post[0].contiguous(), norm=post[1])
         out = _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
         return out if post is None else post[1](post[0] + out)
+    Lk = k_in.shape[1]
     same_qk, same_kv = q_in is k_in, k_in is v_in
     q_in, k_in, v_in = q_in.contiguous(), k_in.contiguous(), v_in.contiguous()
     if same_qk and same_kv:                                 # one projection for q, k, v
