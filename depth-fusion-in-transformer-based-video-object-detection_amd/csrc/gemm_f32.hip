@@ -627,8 +627,13 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
         // 8 waves on a 256 x 128 tile (two workgroups = 4 waves per SIMD, a quarter fewer LDS-DMA pieces per MFMA): 2-3 % ahead of
         // 128 x 128 on the 2048-channel convolutions of layer4 and behind it everywhere else (profiles/r03_gemm_tile256.txt:
         // ffn2 +10 %, layer3 +9-11 %, layer4 conv1 +4 %, the short-K shapes far worse)
-        if (b_is_kn && M % 256 == 0 && M >= 2048 && K >= 512 && t128x128 >= 2048 && g.splits <= 1)
+        if (b_is_kn && M % 256 == 0 && M >= 2048 && K >= 512 && t128x128 >= 8192 && g.splits <= 1)
             return launch<256, 128, 4, 2>(g, batch, b_is_kn, st);
+        // the same convolutions on the 4- or 8-frame block of a rank (2112 / 4224 tiles of 128 x 128): 128 x 64 - twice the
+        // workgroups, more of them resident - is 14-22 % ahead of 256 x 128 and 5-11 % ahead of 128 x 128 at 4 frames, 4-8 % at 8
+        // (tools/r03_exp9.sh, profiles/r03_gemm_tiles_F4_F8.txt)
+        if (b_is_kn && M % 128 == 0 && M >= 2048 && K >= 512 && K <= 1536 && t128x128 >= 2048 && g.splits <= 1)
+            return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
         if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 512)))
             return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     }
@@ -641,6 +646,10 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     // the global-load latency of a K-step but the step before it, so the K loop runs at ~1 us per step whatever its
     // depth; 64-deep steps quarter their number (profiles/r02_rank_step.txt).
     if (t64 <= 320 && K >= 128 && !getenv("DFX_GEMM_NO_DEEP")) return launch<64, 64, 2, 2, 64>(g, batch, b_is_kn, st);
+    // deep 1x1 convolutions of an 8-frame block (layer4 conv1 2048 -> 512, layer2 conv1 512 -> 128): 128 x 64 once it gives
+    // every CU 8 tiles, 4-5 % ahead of 64 x 64 / 64 x 128 there (profiles/r03_gemm_tiles_F4_F8.txt)
+    if (b_is_kn && M % 128 == 0 && K >= 512 && g.splits <= 1 && (long)(M / 128) * ((N + 63) / 64) * zb >= 2048)
+        return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
     if (t128 < 8 * 256 && 0.95 * fill(t64) > fill(t128)) return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }

@@ -143,11 +143,16 @@ class DeformableTransformer(SpatialTransformerBase):
                 setattr(shapes1, attr, getattr(spatial_shapes, attr))
         aux, picks, pick_scores = [], [], []
         final_hs, final_refs = cur_hs, cur_reference_out
+        # The scores do not change between the rounds and top-k comes back sorted: the picks of a round with a smaller k are
+        # a prefix of the picks of the largest one (the reference calls topk on the same ref_prob_concat[:, :, 1] once per round, :530 / :557 / :582; equal scores may come
+        # out in another order - as they may between any two topk implementations), so one selection serves all rounds.
+        kmax = max(TOPK_PER_REF) * R
+        vals_all, idx_all = torch.topk(score, kmax, dim=1)                          # [F,kmax R] in [0, R*Q)
+        rows_all = torch.gather(others, 1, idx_all // Q) * Q + idx_all % Q          # rows of the flat pool
         for i, k in enumerate(TOPK_PER_REF):
-            vals, idx = torch.topk(score, k * R, dim=1)                             # [F,kR] in [0, R*Q)
+            vals, idx, rows = vals_all[:, :k * R], idx_all[:, :k * R], rows_all[:, :k * R]
             picks.append(idx)
             pick_scores.append(vals)
-            rows = torch.gather(others, 1, idx // Q) * Q + idx % Q                 # rows of the flat pool
             tqe = getattr(self, f"temporal_query_layer{i + 1}")
             # the pool is shared by all current frames: its key / value projections are computed once per round and the picks
             # gather projected rows (F x k*R rows of two Linears become T*Q rows of one: 8x fewer at 32 frames), same values

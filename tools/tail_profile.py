@@ -12,7 +12,7 @@ from models.clip_inference import ClipRunner  # noqa: E402
 from models.transformer_layers import make_level_tensors  # noqa: E402
 
 torch.backends.cuda.matmul.allow_tf32 = False
-F_, T, Q, C, S = 8, 32, 300, 256, 4200
+F_, T, Q, C, S = int(os.environ.get("FRAMES", "8")), 32, 300, 256, 4200
 dev = torch.device("cuda")
 model = build(dev, T - 1)
 runner = ClipRunner(model, micro_batch=F_)
