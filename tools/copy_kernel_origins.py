@@ -68,3 +68,35 @@ print("calls per site (all watched ops):")
 for site, c in tot.most_common(45):
     names = ", ".join(f"{n}x{k}" for (n, s2), k in count.items() if s2 == site)
     print(f"{c:5d}  {site:60s} {names[:120]}")
+
+# ---- device-to-device copies the runtime serves with its own copy kernel (`__amd_rocclr_copyBuffer` in a rocprofv3 trace):
+# ATen copy_ / clone / contiguous of same-dtype, densely laid-out operands go through hipMemcpyAsync ----
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+copies = collections.Counter()
+
+
+class CopySpy(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func)
+        if any(k in name for k in ("copy_", "clone", "_to_copy", "contiguous")):
+            src = args[1] if "copy_" in name and len(args) > 1 else args[0]
+            dst = args[0] if "copy_" in name else out
+            if (isinstance(src, torch.Tensor) and isinstance(dst, torch.Tensor) and src.is_cuda and dst.is_cuda
+                    and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()):
+                site = "?"
+                for fr in reversed(traceback.extract_stack(limit=16)[:-1]):
+                    if "depth-fusion-in-transformer" in fr.filename and "tools/" not in fr.filename:
+                        site = fr.filename.split("_amd/")[-1] + ":" + str(fr.lineno)
+                        break
+                copies[(name, site, tuple(src.shape))] += 1
+        return out
+
+
+with CopySpy():
+    step()
+    torch.cuda.synchronize()
+print(f"\ndense same-dtype device copies (memcpy path) in one {F_}-frame rank step: {sum(copies.values())}")
+for (name, site, shape), c in copies.most_common(40):
+    print(f"{c:5d}  {name:28s} {site:58s} {shape}")
