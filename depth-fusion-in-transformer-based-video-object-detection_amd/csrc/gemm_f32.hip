@@ -506,6 +506,95 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     return dfx::check_launch("gemm_f32_kernel");
 }
 
+// ---- Linears over few rows (the 300-query layers: M = 300 x frames of the rank, N and K a few hundred) ----------------------
+// A 64 x 64 tile leaves such a product 76-600 workgroups, each a chain of K / 2 dependent MFMAs per wave behind one memory
+// round trip (K = 256: 3.7 us of MFMAs + ~2 us of latency, whatever the tile: profiles/r03_temporal_timeline_F4.txt).  Here a
+// workgroup owns ONE 32 x 32 tile of C and its NW waves split K: wave w sums k in [w K/NW, (w+1) K/NW) in chunks of 64, every
+// lane loading the 128 contiguous bytes of "its" row of A and of W per chunk straight into the MFMA operand registers (the
+// MFMA sums over k in any order as long as A and B agree: lane (c, h) feeds step 4j + t of a chunk with k = 32h + 4j + t) -
+// no LDS staging, no K loop barrier, all loads of the wave in flight at once - and the NW partial tiles meet in LDS.
+// Same products and the same per-output k order within a wave; the cross-wave sum adds NW partials in wave order.
+template <int NW, int CH>
+__global__ __launch_bounds__(64 * NW) void linear_rows_kernel(const Args g)
+{
+    __shared__ __attribute__((aligned(16))) float red[NW][32][36];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int bx = blockIdx.x % g.nx, by = blockIdx.x / g.nx;
+    const int m0 = by * 32, n0 = bx * 32;
+    constexpr unsigned kOut = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, (int)(((long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A2 ? g.A2 : g.A), 0, (int)(((long)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B), 0, (int)(((long)(g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
+    const int kw = wave * (CH * 64) + 32 * h;                      // first k of this lane in chunk 0
+    const unsigned oa = m0 + c < g.M ? ((unsigned)(m0 + c) * (unsigned)g.lda + (unsigned)kw) * 4u : kOut;
+    const unsigned ob = n0 + c < g.N ? ((unsigned)(n0 + c) * (unsigned)g.ldb + (unsigned)kw) * 4u : kOut;
+    f32x4 a[CH][8], b[CH][8];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[ch][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, (ch * 64 + j * 4) * 4, 0));
+            b[ch][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ob, (ch * 64 + j * 4) * 4, 0));
+        }
+    if (g.A2) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                a[ch][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, oa, (ch * 64 + j * 4) * 4, 0));
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch][j][t], b[ch][j][t], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+        const int row = tid >> 3, c4 = (tid & 7) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m < g.M && n < g.N) {
+            float4 v = *reinterpret_cast<const float4 *>(&red[0][row][c4]);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float4 q = *reinterpret_cast<const float4 *>(&red[w][row][c4]);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            if (g.bias) { const float4 q = *reinterpret_cast<const float4 *>(g.bias + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (g.R) { const float4 q = *reinterpret_cast<const float4 *>(g.R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
+            *reinterpret_cast<float4 *>(g.C + (long)m * g.ldc + n) = v;
+        }
+    }
+}
+
+// few rows, [N,K] operand, plain row-major operands and epilogue: K = 64 * NW * CH
+bool rows_kernel_applies(const Args &g, int batch, int b_is_kn)
+{
+    return !getenv("DFX_GEMM_NO_ROWS") && !b_is_kn && batch == 1 && g.splits <= 1 && !g.mask && !g.cblk && !g.ablk_stride && !g.B2 && !g.ln_g &&
+           g.wide_epilogue && !g.bias_per_row && g.M <= 4800 && g.N % 32 == 0 && g.N <= 1024 &&
+           (g.K == 256 || g.K == 512 || g.K == 1024) && (long)((g.M + 31) / 32) * (g.N / 32) <= 4800;
+}
+
+int launch_rows(const Args &g_in, hipStream_t st)
+{
+    Args g = g_in;
+    g.nx = g.N / 32;
+    g.ny = (g.M + 31) / 32;
+    const dim3 grid((unsigned)(g.nx * g.ny));
+    const long flops = 2L * g.M * g.N * g.K;
+    if (g.K == 256) dfx::launch_timed(flops, -2, 32032, linear_rows_kernel<4, 1>, grid, dim3(256), 0, st, g);
+    else if (g.K == 512) dfx::launch_timed(flops, -2, 32032, linear_rows_kernel<8, 1>, grid, dim3(512), 0, st, g);
+    else dfx::launch_timed(flops, -2, 32032, linear_rows_kernel<8, 2>, grid, dim3(512), 0, st, g);
+    return dfx::check_launch("linear_rows_kernel");
+}
+
 int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st);
 
 }  // namespace
@@ -600,6 +689,7 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
 {
     const int M = g.M, N = g.N, K = g.splits > 1 ? g.kper : g.K;
     const long zb = (long)batch * (g.splits > 1 ? g.splits : 1);
+    if (rows_kernel_applies(g, batch, b_is_kn)) return launch_rows(g, st);
     // tile choice.  Small M / N pick the matching narrow tile.
     if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128
         if (force[0] == '0') return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);

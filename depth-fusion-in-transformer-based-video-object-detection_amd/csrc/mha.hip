@@ -17,8 +17,14 @@
 // = per lane pair (l, l^32): one cross-lane exchange per tile for the maximum, one at the end for l;
 // rescaling O^T is a per-lane scalar multiply.  Likewise the first product sums d in the order
 // lane half 0: d = 0..15, half 1: d = 16..31, so a lane's 16 K operands are 4 ds_read_b128.
+//
+// Few (batch element, head) pairs - the block of a rank that owns 4 or 8 frames of a clip: 160-320 workgroups, each walking
+// up to 78 key tiles one after another - leave the chip half empty and the launch latency-bound.  GROUPS > 1 puts GROUPS wave
+// groups on the same 64 queries, group g taking key tiles g, g + GROUPS, ... with its own LDS tiles; the partial (O^T, m, l)
+// meet in LDS at the end and group 0 merges them with the usual log-sum-exp rescaling (same result up to the order of the sums).
 #include "dfx_common.h"
 #include "dfx_mha.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,15 +34,21 @@ constexpr int TK = 32;         // keys per tile
 constexpr int KP = 36;         // K tile row pitch (floats): 9 sixteen-byte slots, conflict-free ds_read_b128
 constexpr int WAVES = 2;       // 64 queries per workgroup
 
-__global__ __launch_bounds__(64 * WAVES) void mha_fwd(const float *__restrict__ q, long q_batch, long q_row,
+template <int GROUPS>
+__global__ __launch_bounds__(64 * WAVES * GROUPS) void mha_fwd(const float *__restrict__ q, long q_batch, long q_row,
                                                       const float *__restrict__ k, long k_batch, long k_row,
                                                       const float *__restrict__ v, long v_batch, long v_row,
                                                       float *__restrict__ out, long o_batch, long o_row, int Lq,
                                                       int Lk, float scale)
 {
-    __shared__ __attribute__((aligned(16))) float ks[TK][KP];
-    __shared__ __attribute__((aligned(16))) float vs[TK][D];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int GT = 64 * WAVES;                                     // threads of a wave group
+    constexpr int TILE = TK * KP + TK * D;                             // floats of a group's K and V tiles
+    constexpr int MERGE = (GROUPS - 1) * WAVES * 18 * 64;              // partial results of groups 1.. (re-uses the tiles' space)
+    __shared__ __attribute__((aligned(16))) float smem[GROUPS * TILE > MERGE ? GROUPS * TILE : MERGE];
+    const int group = __builtin_amdgcn_readfirstlane((int)threadIdx.x / GT);
+    float (*const ks)[KP] = reinterpret_cast<float (*)[KP]>(smem + group * TILE);
+    float (*const vs)[D] = reinterpret_cast<float (*)[D]>(smem + group * TILE + TK * KP);
+    const int tid = threadIdx.x - group * GT, lane = tid & 63, wave = tid >> 6;      // within the group
     const int col = lane & 31, half = lane >> 5;
     const int hd = blockIdx.y, b = blockIdx.z;
     const int qi = (blockIdx.x * WAVES + wave) * 32 + col;            // this lane's query
@@ -56,8 +68,11 @@ __global__ __launch_bounds__(64 * WAVES) void mha_fwd(const float *__restrict__ 
     float m = -INFINITY, lsum = 0.f;                                   // lsum: this lane half's part of the denominator
     const float *kb = k + b * k_batch + hd * D, *vb = v + b * v_batch + hd * D;
 
-    for (int j0 = 0; j0 < Lk; j0 += TK) {
+    const int ntiles = (Lk + TK - 1) / TK, iters = (ntiles + GROUPS - 1) / GROUPS;
+    for (int it = 0; it < iters; ++it) {
+        const int j0 = (it * GROUPS + group) * TK;                     // (scalar) this group's tile of the round
         __syncthreads();                                               // everyone is done with the previous tile
+        if (j0 < Lk) {
 #pragma unroll
         for (int u = 0; u < (TK * D / 4) / (64 * WAVES); ++u) {
             const int e = tid + u * 64 * WAVES, r = e >> 3, c = e & 7;
@@ -65,7 +80,9 @@ __global__ __launch_bounds__(64 * WAVES) void mha_fwd(const float *__restrict__ 
             *reinterpret_cast<float4 *>(&ks[r][c * 4]) = *reinterpret_cast<const float4 *>(kb + (long)j * k_row + c * 4);
             *reinterpret_cast<float4 *>(&vs[r][c * 4]) = *reinterpret_cast<const float4 *>(vb + (long)j * v_row + c * 4);
         }
+        }
         __syncthreads();
+        if (j0 >= Lk) continue;                                        // (a group without a tile in the last round)
         // ---- S^T = K Q^T: A = K[key = col][16*half + t], B = qv[t] ----
         float ka[16];
 #pragma unroll
@@ -105,7 +122,31 @@ __global__ __launch_bounds__(64 * WAVES) void mha_fwd(const float *__restrict__ 
             o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s[r], o, 0, 0, 0);
         }
     }
-    const float l = lsum + __shfl_xor(lsum, 32);
+    float l = lsum + __shfl_xor(lsum, 32);
+    if (GROUPS > 1) {
+        // groups 1.. leave (O^T, m, l) of their keys in LDS; group 0 folds them in: O = sum_g O_g e^(m_g - m), l likewise
+        __syncthreads();                                               // the tiles are no longer read
+        if (group > 0) {
+            float *mine = smem + ((group - 1) * WAVES + wave) * 18 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64] = o[r];
+            mine[16 * 64] = m;
+            mine[17 * 64] = l;
+        }
+        __syncthreads();
+        if (group > 0) return;
+#pragma unroll
+        for (int gq = 1; gq < GROUPS; ++gq) {
+            const float *p = smem + ((gq - 1) * WAVES + wave) * 18 * 64 + lane;
+            const float mg = p[16 * 64], lg = p[17 * 64];
+            const float mn = fmaxf(m, mg);                             // m is finite: group 0 owns tile 0
+            const float a = __expf(m - mn), bq = __expf(mg - mn);      // bq = 0 for a group that saw no key (m_g = -inf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = o[r] * a + p[r * 64] * bq;
+            l = l * a + lg * bq;
+            m = mn;
+        }
+    }
     if (qi < Lq) {
         const float inv = 1.f / l;
         float *op = out + b * o_batch + (long)qi * o_row + hd * D;
@@ -133,7 +174,19 @@ extern "C" int dfx_mha_f32(const float *q, long q_batch, long q_row, const float
         return dfx::fail(DFX_EINVAL, "mha: row strides smaller than heads * 32");
     if (B > 65535 || heads > 65535) return dfx::fail(DFX_ERANGE, "mha: grid too large");
     const dim3 grid((unsigned)((Lq + 32 * WAVES - 1) / (32 * WAVES)), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(mha_fwd, grid, dim3(64 * WAVES), 0, static_cast<hipStream_t>(stream), q, q_batch, q_row, k,
-                       k_batch, k_row, v, v_batch, v_row, out, o_batch, o_row, Lq, Lk, scale);
+    // wave groups over the keys while the launch leaves CUs idle (see the head of the file); DFX_MHA_GROUPS=1/2/4 forces
+    const long blocks = (long)grid.x * grid.y * grid.z;
+    int groups = Lk >= 128 && blocks <= 400 ? 4 : Lk >= 128 && blocks <= 800 ? 2 : 1;
+    if (const char *f = getenv("DFX_MHA_GROUPS")) groups = f[0] == '4' ? 4 : f[0] == '2' ? 2 : 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (groups == 4)
+        hipLaunchKernelGGL(mha_fwd<4>, grid, dim3(64 * WAVES * 4), 0, st, q, q_batch, q_row, k, k_batch, k_row, v, v_batch, v_row,
+                           out, o_batch, o_row, Lq, Lk, scale);
+    else if (groups == 2)
+        hipLaunchKernelGGL(mha_fwd<2>, grid, dim3(64 * WAVES * 2), 0, st, q, q_batch, q_row, k, k_batch, k_row, v, v_batch, v_row,
+                           out, o_batch, o_row, Lq, Lk, scale);
+    else
+        hipLaunchKernelGGL(mha_fwd<1>, grid, dim3(64 * WAVES), 0, st, q, q_batch, q_row, k, k_batch, k_row, v, v_batch, v_row,
+                           out, o_batch, o_row, Lq, Lk, scale);
     return dfx::check_launch("mha_fwd");
 }

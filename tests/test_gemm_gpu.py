@@ -40,12 +40,48 @@ def test_linear_matches_fp64(M, N, K, variant):
     assert (got.double() - want).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1200, 256, 256), (300, 96, 256), (2400, 512, 512), (37, 256, 1024), (4800, 32, 256),
+                                   (1201, 480, 1024)])
+@pytest.mark.parametrize("variant", ["plain", "bias_relu", "add_res_gelu"])
+def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, monkeypatch):
+    """Few rows (the 300-query layers): one 32 x 32 tile per workgroup, K split over its waves (csrc/gemm_f32.hip,
+    linear_rows_kernel) - against fp64 and against the tile kernel on the same operands (DFX_GEMM_NO_ROWS=1)."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda() if variant != "plain" else None
+    res = torch.randn(M, N, generator=g).cuda() if variant == "add_res_gelu" else None
+    add = torch.randn(M, K, generator=g).cuda() if variant == "add_res_gelu" else None
+    act = {"plain": None, "bias_relu": "relu", "add_res_gelu": "gelu"}[variant]
+    ops.profile_start()
+    got = ops.linear(x, w, b, residual=res, add=add, act=act)
+    tiles = [tb for (_, _, ta, tb) in ops.profile_stop() if ta == -2]
+    assert tiles == [32032], "the rows kernel serves this shape"
+    monkeypatch.setenv("DFX_GEMM_NO_ROWS", "1")
+    other = ops.linear(x, w, b, residual=res, add=add, act=act)
+    monkeypatch.delenv("DFX_GEMM_NO_ROWS")
+    y = (x.double() + (add.double() if add is not None else 0)) @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if res is not None:
+        y = y + res.double()
+    want = y.relu() if act == "relu" else torch.nn.functional.gelu(y) if act == "gelu" else y
+    tol = 4e-6 * K ** 0.5 * (2.0 if add is not None else 1.0)
+    assert (got.double() - want).abs().max().item() < tol
+    assert (got - other).abs().max().item() < tol
+    for _ in range(5):                                   # run-to-run: same bits
+        assert torch.equal(ops.linear(x, w, b, residual=res, add=add, act=act), got)
+
+
 @pytest.mark.parametrize("M,N,K,w", [(4200, 256, 256, 4), (8400, 96, 256, 12), (333, 96, 64, 12), (130, 256, 260, 8),
                                      (5, 12, 8, 4)])
-def test_linear_block_major_layouts(M, N, K, w):
+def test_linear_block_major_layouts(M, N, K, w, monkeypatch):
     """col_block stores C as [N/w][M][w]; x_blocked reads A as [K/4][M][4] - the layouts between the
-    projections and the level-in-LDS MSDA kernel.  Same arithmetic as the row-major call: equal bits."""
+    projections and the level-in-LDS MSDA kernel.  Same arithmetic as the row-major call of the tile kernel: equal bits
+    (the few-row kernel, which serves row-major operands only, sums K in another order: kept out of the comparison)."""
     from dfx import ops
+    monkeypatch.setenv("DFX_GEMM_NO_ROWS", "1")
     g = torch.Generator().manual_seed(M * 7 + N + K + w)
     x = torch.randn(M, K, generator=g).cuda()
     wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
@@ -126,10 +162,14 @@ def test_box_refine_matches_torch(rows, ref_dim):
 
 @pytest.mark.parametrize("B,Lq,Lk,mode", [(2, 300, 300, "self_pos"), (3, 300, 2480, "cross"), (4, 100, 100, "same"),
                                           (1, 65, 33, "cross"), (2, 1, 1, "same"), (2, 64, 32, "self_pos"),
-                                          (1, 31, 95, "cross")])
-def test_fused_mha_matches_module(B, Lq, Lk, mode):
-    """models/fused_mha.py (GEMM projections + csrc/mha.hip) against nn.MultiheadAttention in eval mode."""
+                                          (1, 31, 95, "cross"), (40, 300, 300, "same")])
+@pytest.mark.parametrize("groups", [None, "1", "2", "4"])
+def test_fused_mha_matches_module(B, Lq, Lk, mode, groups, monkeypatch):
+    """models/fused_mha.py (GEMM projections + csrc/mha.hip) against nn.MultiheadAttention in eval mode; the key range split
+    over 1 / 2 / 4 wave groups of a workgroup (None: the launch's own choice)."""
     from models import fused_mha
+    if groups is not None:
+        monkeypatch.setenv("DFX_MHA_GROUPS", groups)
     torch.manual_seed(B * 1000 + Lq + Lk)
     mod = torch.nn.MultiheadAttention(256, 8, dropout=0.1).cuda().eval()
     with torch.no_grad():
