@@ -566,10 +566,22 @@ __global__ __launch_bounds__(64 * NW) void linear_rows_kernel(const Args g)
                 const float4 q = *reinterpret_cast<const float4 *>(&red[w][row][c4]);
                 v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
             }
-            if (g.bias) { const float4 q = *reinterpret_cast<const float4 *>(g.bias + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            if (g.R) { const float4 q = *reinterpret_cast<const float4 *>(g.R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
-            *reinterpret_cast<float4 *>(g.C + (long)m * g.ldc + n) = v;
+            if (g.wide_epilogue && n + 3 < g.N) {
+                if (g.bias) { const float4 q = *reinterpret_cast<const float4 *>(g.bias + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (g.R) { const float4 q = *reinterpret_cast<const float4 *>(g.R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                if (g.relu) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
+                *reinterpret_cast<float4 *>(g.C + (long)m * g.ldc + n) = v;
+            } else {                                           // narrow heads (class / box / reference-point Linears: N = 2 .. 4)
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n + u >= g.N) break;
+                    float x = e[u] + (g.bias ? g.bias[n + u] : 0.f);
+                    if (g.R) x += g.R[(long)m * g.ldr + n + u];
+                    if (g.relu) x = activate(x, g.relu);
+                    g.C[(long)m * g.ldc + n + u] = x;
+                }
+            }
         }
     }
 }
@@ -577,15 +589,18 @@ __global__ __launch_bounds__(64 * NW) void linear_rows_kernel(const Args g)
 // few rows, [N,K] operand, plain row-major operands and epilogue: K = 64 * NW * CH
 bool rows_kernel_applies(const Args &g, int batch, int b_is_kn)
 {
-    return !getenv("DFX_GEMM_NO_ROWS") && !b_is_kn && batch == 1 && g.splits <= 1 && !g.mask && !g.cblk && !g.ablk_stride && !g.B2 && !g.ln_g &&
-           g.wide_epilogue && !g.bias_per_row && g.M <= 4800 && g.N % 32 == 0 && g.N <= 1024 &&
-           (g.K == 256 || g.K == 512 || g.K == 1024) && (long)((g.M + 31) / 32) * (g.N / 32) <= 4800;
+    static const char *mx = getenv("DFX_GEMM_ROWS_MAX");          // tuning aid: the row limit (0 = kernel off)
+    const int max_rows = getenv("DFX_GEMM_NO_ROWS") ? 0 : mx ? atoi(mx) : 4800;
+    const int tiles_n = (g.N + 31) / 32;
+    return !b_is_kn && batch == 1 && g.splits <= 1 && !g.mask && !g.cblk && !g.ablk_stride && !g.B2 && !g.ln_g &&
+           !g.bias_per_row && g.M <= max_rows && (g.N <= 32 || (g.N % 32 == 0 && g.wide_epilogue)) && g.N <= 1024 &&
+           (g.K == 256 || g.K == 512 || g.K == 1024) && (long)((g.M + 31) / 32) * tiles_n <= 9600;
 }
 
 int launch_rows(const Args &g_in, hipStream_t st)
 {
     Args g = g_in;
-    g.nx = g.N / 32;
+    g.nx = (g.N + 31) / 32;
     g.ny = (g.M + 31) / 32;
     const dim3 grid((unsigned)(g.nx * g.ny));
     const long flops = 2L * g.M * g.N * g.K;

@@ -41,7 +41,7 @@ def test_linear_matches_fp64(M, N, K, variant):
 
 
 @pytest.mark.parametrize("M,N,K", [(1200, 256, 256), (300, 96, 256), (2400, 512, 512), (37, 256, 1024), (4800, 32, 256),
-                                   (1201, 480, 1024)])
+                                   (1201, 480, 1024), (1200, 4, 256), (700, 3, 1024), (64, 2, 512), (1200, 1024, 256)])
 @pytest.mark.parametrize("variant", ["plain", "bias_relu", "add_res_gelu"])
 def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, monkeypatch):
     """Few rows (the 300-query layers): one 32 x 32 tile per workgroup, K split over its waves (csrc/gemm_f32.hip,
