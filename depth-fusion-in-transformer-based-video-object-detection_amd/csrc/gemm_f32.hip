@@ -58,6 +58,7 @@ struct Args {
     int group_m;          // tile order (placement only, never results): 0 = n fastest, then m, then z, as dispatched;
                           // > 0: workgroup ids are XCD-remapped (each XCD walks one contiguous range) and run m fastest inside
                           // groups of group_m tile rows, then along the columns of every batch element
+    int fast_epi;         // wide epilogue in its lean form (set by launch(): no LayerNorm / GELU / act_first, C and R slices < 2 GiB)
 };
 
 __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: exact (erf) GELU
@@ -65,8 +66,18 @@ __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: 
     return act == 1 ? fmaxf(v, 0.f) : 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
 }
 
+// waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument; what the K loop's own
+// needs allow: 168 / 120 / 96 / 64 registers per lane for the 128 x 128 / 64 x 128 / 128 x 64 / 64 x 64 tiles, two 8-wave
+// workgroups of the 256 x 128 tile; without the bound the scheduler hoists the epilogue's loads over everything and takes
+// 2-3x the registers, i.e. a third of the resident waves)
+constexpr int min_blocks(int BM, int BN, int NW)
+{
+    return NW == 8 ? 4 : BM == 64 && BN == 256 ? 3 : BM == 128 && BN == 128 ? 3 : BM == 64 && BN == 128 ? 4
+           : BM == 128 && BN == 64 ? 5 : BM == 64 && BN == 64 ? 6 : BM == 128 && BN == 96 ? 3 : BM == 128 && BN == 32 ? 6 : 1;
+}
+
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK, bool DMA>
-__global__ __launch_bounds__(64 * WM * WN, (BM == 64 && BN == 256) ? 3 : 1) void gemm_f32_kernel(const Args g)
+__global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN)) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int LDK = BK + 4;                       // [m][k] / [n][k] pitch: 5 (BK = 16) sixteen-byte slots
@@ -371,10 +382,79 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 64 && BN == 256) ? 3 : 1) void
     }
 
     // ---- epilogue ----
+#if defined(DFX_GEMM_ABLATE_EPILOGUE)          // timing ablation (tools/r03_exp14.sh): one store per lane keeps the K loop alive
+    if (g.M > 0) { g.C[(long)blockIdx.x * NTHR + tid] = acc[0][0][0] + acc[MT - 1][NT - 1][15]; return; }
+#endif
     float *C = g.C + cz * g.strideC;
     const float *R = g.R ? g.R + bz * g.strideR : nullptr;
     const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
     const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
+    constexpr int CQ = BN / 4;                                 // float4 per tile row
+    if constexpr (NTHR % CQ == 0) if (g.wide_epilogue && g.fast_epi) {
+        // The lean form of the wide epilogue below (same LDS round trip, same float4 rows).  An ablation that ends the tile
+        // after the K loop (tools/r03_exp14.sh, profiles/r03_gemm_epilogue_ablation.txt) showed the epilogue costing 13-16 % of
+        // a K = 256 launch and 4-5 % of a K = 1024 one - its vector instructions take issue slots from the other resident
+        // workgroups' MFMAs - so it is cut to the instructions it needs: every wave writes one 32-row tile per pass (was:
+        // half of the waves two tiles, the others idle), a thread keeps its column quad (bias loaded once), stores and
+        // residual loads go through buffer descriptors with 32-bit offsets (rows / columns outside the problem get an offset
+        // beyond the extent: no branches).
+        float *Ct = smem;
+        constexpr int TPP = PR / (32 * WM);                   // 32-row tiles a wave writes per pass (0: keep the row-range passes)
+        constexpr bool BAL = TPP >= 1 && PR == TPP * 32 * WM && MT % (TPP >= 1 ? TPP : 1) == 0;
+        constexpr int RS = NTHR / CQ, NIT = PR / RS;          // rows between a thread's float4s, float4s per thread and pass
+        static_assert(PR % RS == 0, "a pass is a whole number of thread rows");
+        const int c4 = tid % CQ, r0 = tid / CQ;
+        const int n = n0 + c4 * 4;
+        const bool ncol = n < g.N;
+        float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bcol && ncol) bc = *reinterpret_cast<const float4 *>(g.bias + n);
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((long)(g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : C), 0, (int)(((long)(g.M - 1) * (R ? g.ldr : g.ldc) + g.N) * 4), 0x00020000);
+        const bool r_direct = R && !(PREFETCH_R && use_rpre);
+#pragma unroll
+        for (int p = 0; p < BM / PR; ++p) {
+            // rows of this pass a thread handles, and the residual on its way while the tile goes through LDS
+            int mrow[NIT];
+            f32x4 rr[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = r0 + it * RS;
+                mrow[it] = BAL ? m0 + (row / (32 * (TPP >= 1 ? TPP : 1))) * TM + p * (TPP >= 1 ? TPP : 1) * 32 + row % (32 * (TPP >= 1 ? TPP : 1))
+                               : m0 + p * PR + row;
+                if (r_direct) {
+                    const unsigned o = (mrow[it] < g.M && ncol) ? ((unsigned)mrow[it] * (unsigned)g.ldr + (unsigned)n) * 4u : 0x80000000u;
+                    rr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, o, 0, 0));
+                }
+            }
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (BAL ? i / (TPP >= 1 ? TPP : 1) != p : (wm * TM + i * 32) / PR != p) continue;      // compile-time / wave-uniform
+                const int rbase = (BAL ? (wm * TPP + i % (TPP >= 1 ? TPP : 1)) * 32 : wm * TM + i * 32 - p * PR) + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        Ct[(rbase + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = r0 + it * RS, m = mrow[it];
+                float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
+                v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w;
+                if (brow) { const float b = g.bias[min(m, g.M - 1)]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                if (PREFETCH_R && use_rpre) { const f32x4 q = rpre[PREFETCH_R ? it : 0]; v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
+                else if (r_direct) { v.x += rr[it][0]; v.y += rr[it][1]; v.z += rr[it][2]; v.w += rr[it][3]; }
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (mask && mask[min(m, g.M - 1)]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const unsigned o = (m < g.M && ncol) ? ((unsigned)m * (unsigned)g.ldc + (unsigned)n) * 4u : 0x80000000u;
+                const f32x4 w = {v.x, v.y, v.z, v.w};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), rsC, o, 0, 0);
+            }
+        }
+        return;
+    }
     if (g.wide_epilogue) {
         // Row-major C with 16-byte aligned rows: the accumulators (a lane holds one column of 16 scattered rows) go
         // through LDS, 64 tile rows at a time, and leave as float4 per lane - a wave-instruction then covers whole
@@ -483,6 +563,8 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     const long total = (long)g.nx * g.ny * batch * (g.splits > 1 ? g.splits : 1);
     if (total >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: too many tiles");
     g.group_m = tile_group(g, batch);
+    g.fast_epi = g.wide_epilogue && !g.ln_g && !g.act_first && g.relu != 2 && ((long)(g.M - 1) * g.ldc + g.N) * 4 < (1L << 31) &&
+                 (!g.R || ((long)(g.M - 1) * g.ldr + g.N) * 4 < (1L << 31)) && !getenv("DFX_GEMM_OLD_EPILOGUE");
     const dim3 grid((unsigned)total), block(64 * WM * WN);
     // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
     // or -2 (Linear), tag_b = tile
