@@ -23,6 +23,7 @@
 #include "dfx_common.h"
 #include "dfx_gemm.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -70,14 +71,14 @@ __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: 
 // needs allow: 168 / 120 / 96 / 64 registers per lane for the 128 x 128 / 64 x 128 / 128 x 64 / 64 x 64 tiles, two 8-wave
 // workgroups of the 256 x 128 tile; without the bound the scheduler hoists the epilogue's loads over everything and takes
 // 2-3x the registers, i.e. a third of the resident waves)
-constexpr int min_blocks(int BM, int BN, int NW)
+constexpr int min_blocks(int BM, int BN, int NW, int BK)
 {
-    return NW == 8 ? 4 : BM == 64 && BN == 256 ? 3 : BM == 128 && BN == 128 ? 3 : BM == 64 && BN == 128 ? 4
+    return BK != 16 ? 1 : NW == 8 ? 4 : BM == 64 && BN == 256 ? 3 : BM == 128 && BN == 128 ? 3 : BM == 64 && BN == 128 ? 4
            : BM == 128 && BN == 64 ? 5 : BM == 64 && BN == 64 ? 6 : BM == 128 && BN == 96 ? 3 : BM == 128 && BN == 32 ? 6 : 1;
 }
 
 template <int BM, int BN, int WM, int WN, bool B_KN, int BK, bool DMA>
-__global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN)) void gemm_f32_kernel(const Args g)
+__global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void gemm_f32_kernel(const Args g)
 {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int LDK = BK + 4;                       // [m][k] / [n][k] pitch: 5 (BK = 16) sixteen-byte slots
@@ -394,65 +395,92 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN)) void gem
         // The lean form of the wide epilogue below (same LDS round trip, same float4 rows).  An ablation that ends the tile
         // after the K loop (tools/r03_exp14.sh, profiles/r03_gemm_epilogue_ablation.txt) showed the epilogue costing 13-16 % of
         // a K = 256 launch and 4-5 % of a K = 1024 one - its vector instructions take issue slots from the other resident
-        // workgroups' MFMAs - so it is cut to the instructions it needs: every wave writes one 32-row tile per pass (was:
-        // half of the waves two tiles, the others idle), a thread keeps its column quad (bias loaded once), stores and
-        // residual loads go through buffer descriptors with 32-bit offsets (rows / columns outside the problem get an offset
-        // beyond the extent: no branches).
+        // workgroups' MFMAs - so it is cut to the instructions it needs:
+        //   every wave writes one 32-row tile per pass (was: half of the waves two tiles, the others idle);
+        //   a thread keeps its column quad (column bias loaded once) and its rows are m = (m0 + r0) + D(pass, it) with D known
+        //   at compile time, so a store / residual / row-bias offset is one add to a per-thread base; C, R, the row bias and
+        //   the row mask go through buffer descriptors of their exact extents: rows beyond M fall past the extent (loads
+        //   return 0, stores are dropped), columns beyond N start from an offset beyond everything - no compares, no selects;
+        //   the body is compiled per (bias kind, residual, mask) instead of selecting at run time; ReLU is one v_max each.
         float *Ct = smem;
         constexpr int TPP = PR / (32 * WM);                   // 32-row tiles a wave writes per pass (0: keep the row-range passes)
-        constexpr bool BAL = TPP >= 1 && PR == TPP * 32 * WM && MT % (TPP >= 1 ? TPP : 1) == 0;
+        constexpr int TP1 = TPP >= 1 ? TPP : 1;
+        constexpr bool BAL = TPP >= 1 && PR == TPP * 32 * WM && MT % TP1 == 0;
         constexpr int RS = NTHR / CQ, NIT = PR / RS;          // rows between a thread's float4s, float4s per thread and pass
-        static_assert(PR % RS == 0, "a pass is a whole number of thread rows");
+        static_assert(PR % RS == 0 && (!BAL || (32 * TP1) % RS == 0), "a pass is a whole number of thread rows");
         const int c4 = tid % CQ, r0 = tid / CQ;
-        const int n = n0 + c4 * 4;
+        const int n = n0 + c4 * 4, mb = m0 + r0;
+        constexpr unsigned kPast = 0x80000000u;
         const bool ncol = n < g.N;
-        float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bcol && ncol) bc = *reinterpret_cast<const float4 *>(g.bias + n);
+        const unsigned cbase = ncol ? ((unsigned)mb * (unsigned)g.ldc + (unsigned)n) * 4u : kPast;
+        const unsigned rbase_off = ncol ? ((unsigned)mb * (unsigned)g.ldr + (unsigned)n) * 4u : kPast;
         const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((long)(g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : C), 0, (int)(((long)(g.M - 1) * (R ? g.ldr : g.ldc) + g.N) * 4), 0x00020000);
-        const bool r_direct = R && !(PREFETCH_R && use_rpre);
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.bias ? g.bias : C), 0, g.M * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsMask = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(mask ? mask : reinterpret_cast<const unsigned char *>(C)), 0, g.M, 0x00020000);
+        const int relu = g.relu;
+        auto run = [&](auto bias_kind, auto has_r, auto has_mask) {
+            constexpr int BIAS = decltype(bias_kind)::value;          // 0 none, 1 per column, 2 per row
+            constexpr bool HAS_R = decltype(has_r)::value, HAS_MASK = decltype(has_mask)::value;
+            f32x4 bc = {0.f, 0.f, 0.f, 0.f};
+            if (BIAS == 1 && ncol) bc = *reinterpret_cast<const f32x4 *>(g.bias + n);
+            const bool r_pre = HAS_R && PREFETCH_R && use_rpre;
 #pragma unroll
-        for (int p = 0; p < BM / PR; ++p) {
-            // rows of this pass a thread handles, and the residual on its way while the tile goes through LDS
-            int mrow[NIT];
-            f32x4 rr[NIT];
+            for (int p = 0; p < BM / PR; ++p) {
+                // the residual, row bias and mask of this pass on their way while the tile goes through LDS
+                f32x4 rr[HAS_R ? NIT : 1];
+                float br[BIAS == 2 ? NIT : 1];
+                unsigned char mk[HAS_MASK ? NIT : 1];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = r0 + it * RS;
-                mrow[it] = BAL ? m0 + (row / (32 * (TPP >= 1 ? TPP : 1))) * TM + p * (TPP >= 1 ? TPP : 1) * 32 + row % (32 * (TPP >= 1 ? TPP : 1))
-                               : m0 + p * PR + row;
-                if (r_direct) {
-                    const unsigned o = (mrow[it] < g.M && ncol) ? ((unsigned)mrow[it] * (unsigned)g.ldr + (unsigned)n) * 4u : 0x80000000u;
-                    rr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, o, 0, 0));
+                for (int it = 0; it < NIT; ++it) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + p * TP1 * 32 + (it * RS) % (32 * TP1) : p * PR + it * RS;
+                    if (HAS_R && !r_pre)
+                        rr[HAS_R ? it : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase_off + (unsigned)D * (unsigned)g.ldr * 4u, 0, 0));
+                    if (BIAS == 2)
+                        br[BIAS == 2 ? it : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsBias, (unsigned)(mb + D) * 4u, 0, 0));
+                    if (HAS_MASK)
+                        mk[HAS_MASK ? it : 0] = __builtin_amdgcn_raw_buffer_load_b8(rsMask, (unsigned)(mb + D), 0, 0);
+                }
+                if (p > 0) __syncthreads();
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (BAL ? i / TP1 != p : (wm * TM + i * 32) / PR != p) continue;      // compile-time / wave-uniform
+                    const int rb = (BAL ? (wm * TPP + i % TP1) * 32 : wm * TM + i * 32 - p * PR) + 4 * half;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            Ct[(rb + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + p * TP1 * 32 + (it * RS) % (32 * TP1) : p * PR + it * RS;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(&Ct[(r0 + it * RS) * LDC + c4 * 4]);
+                    if (BIAS == 1) v += bc;
+                    if (BIAS == 2) v += br[BIAS == 2 ? it : 0];
+                    if (HAS_R) v += r_pre ? rpre[PREFETCH_R ? it : 0] : rr[HAS_R ? it : 0];
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(v[e]));
+                    }
+                    if (HAS_MASK && mk[HAS_MASK ? it : 0]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rsC,
+                                                           cbase + (unsigned)D * (unsigned)g.ldc * 4u, 0, 0);
                 }
             }
-            if (p > 0) __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                if (BAL ? i / (TPP >= 1 ? TPP : 1) != p : (wm * TM + i * 32) / PR != p) continue;      // compile-time / wave-uniform
-                const int rbase = (BAL ? (wm * TPP + i % (TPP >= 1 ? TPP : 1)) * 32 : wm * TM + i * 32 - p * PR) + 4 * half;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        Ct[(rbase + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = r0 + it * RS, m = mrow[it];
-                float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
-                v.x += bc.x; v.y += bc.y; v.z += bc.z; v.w += bc.w;
-                if (brow) { const float b = g.bias[min(m, g.M - 1)]; v.x += b; v.y += b; v.z += b; v.w += b; }
-                if (PREFETCH_R && use_rpre) { const f32x4 q = rpre[PREFETCH_R ? it : 0]; v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
-                else if (r_direct) { v.x += rr[it][0]; v.y += rr[it][1]; v.z += rr[it][2]; v.w += rr[it][3]; }
-                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (mask && mask[min(m, g.M - 1)]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const unsigned o = (m < g.M && ncol) ? ((unsigned)m * (unsigned)g.ldc + (unsigned)n) * 4u : 0x80000000u;
-                const f32x4 w = {v.x, v.y, v.z, v.w};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), rsC, o, 0, 0);
-            }
-        }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using B2 = std::integral_constant<int, 2>;
+        auto with_bias = [&](auto has_r, auto has_mask) {
+            if (brow) run(B2{}, has_r, has_mask); else if (bcol) run(B1{}, has_r, has_mask); else run(B0{}, has_r, has_mask);
+        };
+        if (mask) { if (R) with_bias(T{}, T{}); else with_bias(F{}, T{}); }
+        else { if (R) with_bias(T{}, F{}); else with_bias(F{}, F{}); }
         return;
     }
     if (g.wide_epilogue) {
@@ -563,8 +591,9 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     const long total = (long)g.nx * g.ny * batch * (g.splits > 1 ? g.splits : 1);
     if (total >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: too many tiles");
     g.group_m = tile_group(g, batch);
-    g.fast_epi = g.wide_epilogue && !g.ln_g && !g.act_first && g.relu != 2 && ((long)(g.M - 1) * g.ldc + g.N) * 4 < (1L << 31) &&
-                 (!g.R || ((long)(g.M - 1) * g.ldr + g.N) * 4 < (1L << 31)) && !getenv("DFX_GEMM_OLD_EPILOGUE");
+    // (row offsets of a tile reach up to BM rows past M before the hardware range check drops them: they must not wrap)
+    g.fast_epi = g.wide_epilogue && !g.ln_g && !g.act_first && g.relu != 2 && ((long)(g.M + BM) * g.ldc + g.N) * 4 < (1L << 31) &&
+                 (!g.R || ((long)(g.M + BM) * g.ldr + g.N) * 4 < (1L << 31)) && !getenv("DFX_GEMM_OLD_EPILOGUE");
     const dim3 grid((unsigned)total), block(64 * WM * WN);
     // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
     // or -2 (Linear), tag_b = tile
