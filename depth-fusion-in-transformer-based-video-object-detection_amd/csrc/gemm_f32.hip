@@ -850,7 +850,10 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
         // (tools/r03_exp9.sh, profiles/r03_gemm_tiles_F4_F8.txt)
         if (b_is_kn && M % 128 == 0 && M >= 2048 && K >= 512 && K <= 1536 && t128x128 >= 2048 && g.splits <= 1)
             return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
-        if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 512)))
+        // (since the lean epilogue - residual on its way while the tile crosses LDS - the short-K convolutions with a residual
+        // take the 128 x 128 tile too once there are 16 tiles per CU: layer1 / layer2 / layer3 conv3 6.6 / 6.9 / 4.5 % faster at
+        // 32 frames, layer1 conv3 10 % at 4 and 8; so do the 256 -> 256 Linears: profiles/r03_gemm_tiles_lean_epilogue.txt)
+        if (rows_fit && t128x128 >= 2048 && (K >= 512 || (K >= 256 && !g.R && N >= 256) || (b_is_kn && t128x128 >= 4096)))
             return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
     }
     // Few tiles (token GEMMs of a 4- or 8-frame rank block): all workgroups are resident at once, the CUs that get
