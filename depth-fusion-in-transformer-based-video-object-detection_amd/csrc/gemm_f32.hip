@@ -59,6 +59,7 @@ struct Args {
     int group_m;          // tile order (placement only, never results): 0 = n fastest, then m, then z, as dispatched;
                           // > 0: workgroup ids are XCD-remapped (each XCD walks one contiguous range) and run m fastest inside
                           // groups of group_m tile rows, then along the columns of every batch element
+    int fast_cblk;        // column-block-major C through the same LDS round trip (set by launch())
     int fast_epi;         // wide epilogue in its lean form (set by launch(): no LayerNorm / GELU / act_first, C and R slices < 2 GiB)
 };
 
@@ -483,6 +484,54 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
         else { if (R) with_bias(T{}, F{}); else with_bias(F{}, F{}); }
         return;
     }
+    if (g.cblk > 0 && g.fast_cblk) {
+        // Column-block-major C ([N / w][M][w], w = 4 or 12: what msda_level_forward reads) through the same LDS round trip: a
+        // pass's float4s are numbered block-major - (block, row, quad of the block), quad fastest - so that consecutive lanes
+        // write consecutive memory (64 rows x w floats of one block per wave-instruction for w = 4) instead of one scattered
+        // dword per lane and accumulator register.
+        float *Ct = smem;
+        constexpr int TPP = PR / (32 * WM), TP1 = TPP >= 1 ? TPP : 1;
+        constexpr bool BAL = TPP >= 1 && PR == TPP * 32 * WM && MT % TP1 == 0;
+        constexpr int NF4 = PR * CQ;                           // float4 per pass
+        const int QB = g.cblk >> 2, b0 = n0 / g.cblk;         // quads per block, first block of the tile
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((long)(g.N / g.cblk - 1) * g.cblk_stride + (long)g.M * g.cblk) * 4), 0x00020000);
+        const int relu = g.relu;
+#pragma unroll
+        for (int p = 0; p < BM / PR; ++p) {
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (BAL ? i / TP1 != p : (wm * TM + i * 32) / PR != p) continue;
+                const int rb = (BAL ? (wm * TPP + i % TP1) * 32 : wm * TM + i * 32 - p * PR) + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        Ct[(rb + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e0 = 0; e0 < NF4; e0 += NTHR) {
+                const int e = e0 + tid;
+                if (NF4 % NTHR != 0 && e >= NF4) break;
+                const int blk = e / (PR * QB), rem = e - blk * (PR * QB), row = rem / QB, sub = rem - row * QB;
+                const int m = BAL ? m0 + (row / (32 * TP1)) * TM + p * TP1 * 32 + row % (32 * TP1) : m0 + p * PR + row;
+                const int q = blk * QB + sub, n = n0 + q * 4;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&Ct[row * LDC + q * 4]);
+                const bool ok = m < g.M && n < g.N;
+                if (bcol) v += *reinterpret_cast<const f32x4 *>(g.bias + min(n, g.N - 4));
+                if (brow) v += g.bias[min(m, g.M - 1)];
+                if (relu) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm("v_max_f32 %0, 0, %1" : "=v"(v[u]) : "v"(v[u]));
+                }
+                if (mask && mask[min(m, g.M - 1)]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const unsigned o = ok ? (unsigned)(((long)(b0 + blk) * g.cblk_stride + (long)m * g.cblk + sub * 4) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rsC, o, 0, 0);
+            }
+        }
+        return;
+    }
     if (g.wide_epilogue) {
         // Row-major C with 16-byte aligned rows: the accumulators (a lane holds one column of 16 scattered rows) go
         // through LDS, 64 tile rows at a time, and leave as float4 per lane - a wave-instruction then covers whole
@@ -591,6 +640,9 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     const long total = (long)g.nx * g.ny * batch * (g.splits > 1 ? g.splits : 1);
     if (total >= (1L << 31)) return dfx::fail(DFX_ERANGE, "gemm: too many tiles");
     g.group_m = tile_group(g, batch);
+    g.fast_cblk = g.cblk > 0 && g.cblk % 4 == 0 && BN % g.cblk == 0 && g.N % g.cblk == 0 && !g.R && g.relu != 2 && !g.ln_g &&
+                  (!g.bias || g.bias_per_row || dfx::aligned16(g.bias)) && dfx::aligned16(g.C) && (g.cblk_stride & 3) == 0 && (g.strideC & 3) == 0 &&
+                  ((long)(g.N / g.cblk) * g.cblk_stride) * 4 < (1L << 31) && !getenv("DFX_GEMM_OLD_EPILOGUE");
     // (row offsets of a tile reach up to BM rows past M before the hardware range check drops them: they must not wrap)
     g.fast_epi = g.wide_epilogue && !g.ln_g && !g.act_first && g.relu != 2 && ((long)(g.M + BM) * g.ldc + g.N) * 4 < (1L << 31) &&
                  (!g.R || ((long)(g.M + BM) * g.ldr + g.N) * 4 < (1L << 31)) && !getenv("DFX_GEMM_OLD_EPILOGUE");
@@ -704,7 +756,7 @@ bool rows_kernel_applies(const Args &g, int batch, int b_is_kn)
     const int max_rows = getenv("DFX_GEMM_NO_ROWS") ? 0 : mx ? atoi(mx) : 4800;
     const int tiles_n = (g.N + 31) / 32;
     return !b_is_kn && batch == 1 && g.splits <= 1 && !g.mask && !g.cblk && !g.ablk_stride && !g.B2 && !g.ln_g &&
-           !g.bias_per_row && g.M <= max_rows && (g.N <= 32 || (g.N % 32 == 0 && g.wide_epilogue)) && g.N <= 1024 &&
+           !g.bias_per_row && (g.M <= max_rows || (max_rows > 0 && g.N <= 128)) && (g.N <= 32 || (g.N % 32 == 0 && g.wide_epilogue)) && g.N <= 1024 &&
            (g.K == 256 || g.K == 512 || g.K == 1024) && (long)((g.M + 31) / 32) * tiles_n <= 9600;
 }
 
