@@ -182,6 +182,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs g)
     }
 
     float *Y = g.Y + bz * g.strideY;
+    if (g.wide && g.act != DFX_ACT_GELU && (long)(g.Co + BM) * P * 4 < (1L << 31)) {
+        // The lean epilogue of gemm_f32.hip (see there: the epilogue's vector instructions are matrix time of the other
+        // resident workgroups): one 32-row tile per wave and pass, a thread keeps its column quad, rows are m0 + r0 + D(pass, it)
+        // with D known at compile time, stores and the row bias through buffer descriptors of the exact extents (rows beyond Co
+        // fall past the extent, columns beyond the map start from an offset beyond everything), ReLU = one v_max each.
+        float *Ct = smem;
+        constexpr int PR = 64, CQ = BN / 4, RS = 256 / CQ, NIT = PR / RS;
+        constexpr int TPP = PR / (32 * WM), TP1 = TPP >= 1 ? TPP : 1;
+        constexpr bool BAL = TPP >= 1 && PR == TPP * 32 * WM && MT % TP1 == 0;
+        static_assert(!BAL || (32 * TP1) % RS == 0, "thread rows must not straddle wave tiles");
+        const int c4 = tid % CQ, r0 = tid / CQ, n = n0 + c4 * 4, mb = m0 + r0;
+        const unsigned cbase = n < P ? ((unsigned)mb * (unsigned)P + (unsigned)n) * 4u : 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long)g.Co * P * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.bias ? g.bias : Y), 0, g.Co * 4, 0x00020000);
+        const bool has_bias = g.bias != nullptr;
+        const int relu = g.act == DFX_ACT_RELU;
+#pragma unroll
+        for (int ps = 0; ps < BM / PR; ++ps) {
+            float br[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + ps * TP1 * 32 + (it * RS) % (32 * TP1) : ps * PR + it * RS;
+                br[it] = has_bias ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsBias, (unsigned)(mb + D) * 4u, 0, 0)) : 0.f;
+            }
+            if (ps > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (BAL ? i / TP1 != ps : (wm * TM + i * 32) / PR != ps) continue;
+                const int rb = (BAL ? (wm * TPP + i % TP1) * 32 : wm * TM + i * 32 - ps * PR) + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        Ct[(rb + (r & 3) + 8 * (r >> 2)) * LDC + wn * TN + j * 32 + c] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + ps * TP1 * 32 + (it * RS) % (32 * TP1) : ps * PR + it * RS;
+                if (m0 + D >= g.Co) continue;                  // (scalar: the whole thread row lies beyond the last output channel)
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&Ct[(r0 + it * RS) * LDC + c4 * 4]);
+                v += br[it];
+                if (relu) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm("v_max_f32 %0, 0, %1" : "=v"(v[u]) : "v"(v[u]));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rsY,
+                                                       cbase + (unsigned)D * (unsigned)P * 4u, 0, 0);
+            }
+        }
+        return;
+    }
     if (g.wide) {
         // as gemm_f32.hip: accumulators through LDS, 64 tile rows at a time, out as float4 - whole 512-byte row segments
         float *Ct = smem;

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + p * TP1 * 32 + (it * RS) % (32 * TP1) : p * PR + it * RS;
+                    if (m0 + D >= g.M) continue;               // (scalar: the whole thread row lies beyond the last row)
                     f32x4 v = *reinterpret_cast<const f32x4 *>(&Ct[(r0 + it * RS) * LDC + c4 * 4]);
                     if (BIAS == 1) v += bc;
                     if (BIAS == 2) v += br[BIAS == 2 ? it : 0];

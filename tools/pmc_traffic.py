@@ -7,7 +7,8 @@ import csv
 import glob
 import sys
 
-FAM = (("gemm_f32_kernel", "gemm_f32_kernel"), ("conv_wino_kernel", "conv_wino_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
+FAM = (("gemm_f32_kernel", "gemm_f32_kernel"), ("gemm_f32_kernel", "linear_rows_kernel"),   # (one family, two kernels)
+       ("conv_wino_kernel", "conv_wino_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
        ("msda_fused_level", "msda_fused_level"))
 
 
@@ -29,7 +30,7 @@ ft, fc = load(sys.argv[1], "FETCH_SIZE")
 wt, wc = load(sys.argv[2], "WRITE_SIZE")
 print("| kernel family | launches / step | 2 x FETCH_SIZE (MB / step) | WRITE_SIZE (MB / step) | HBM traffic (MB / step) | per launch (MB) |")
 print("|---|---|---|---|---|---|")
-for key, _ in FAM:
+for key in dict.fromkeys(k for k, _ in FAM):
     n = fc[key] / steps
     rd, wr = 2 * ft[key] * 1024 / steps / 1e6, wt[key] * 1024 / steps / 1e6
     print(f"| `{key}` | {n:.1f} | {rd:.1f} | {wr:.1f} | {rd + wr:.1f} | {(rd + wr) / max(n, 1):.2f} |")
