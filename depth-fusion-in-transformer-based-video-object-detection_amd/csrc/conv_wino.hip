@@ -362,8 +362,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
                 t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
             }
             const float bv = g.bias ? g.bias[co] : 0.f;
-            const float y00 = activate(t0[0] + t0[1] + t0[2] + bv, g.act), y01 = activate(t0[1] - t0[2] - t0[3] + bv, g.act);
-            const float y10 = activate(t1[0] + t1[1] + t1[2] + bv, g.act), y11 = activate(t1[1] - t1[2] - t1[3] + bv, g.act);
+            float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+            float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+            // one scalar branch per item instead of a chain per value (the epilogue's vector instructions are matrix time of
+            // the other waves, gemm_f32.hip): ReLU is one v_max each, the GELU polynomial stays out of the way
+            if (g.act == DFX_ACT_RELU) {
+                asm("v_max_f32 %0, 0, %1" : "=v"(y00) : "v"(y00));
+                asm("v_max_f32 %0, 0, %1" : "=v"(y01) : "v"(y01));
+                asm("v_max_f32 %0, 0, %1" : "=v"(y10) : "v"(y10));
+                asm("v_max_f32 %0, 0, %1" : "=v"(y11) : "v"(y11));
+            } else if (g.act == DFX_ACT_GELU) {
+                y00 = activate(y00, DFX_ACT_GELU); y01 = activate(y01, DFX_ACT_GELU);
+                y10 = activate(y10, DFX_ACT_GELU); y11 = activate(y11, DFX_ACT_GELU);
+            }
             if (tv && y0 < g.H && x0 < g.W) {        // (a dilated map's last tile row / column can lie outside it)
                 float *yp = Y + (long)co * P + y0 * g.W + x0;
                 const bool xv = x0 + d < g.W, yv = y0 + d < g.H;
