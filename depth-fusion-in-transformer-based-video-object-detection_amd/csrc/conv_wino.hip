@@ -220,8 +220,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         float xr[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float lo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own1[i]), 0x138, 0xf, 0xf, false));  // wave_shr:1
-            float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, own0[i]), 0x130, 0xf, 0xf, false));  // wave_shl:1
+            float lo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1[i]), 0x138, 0xf, 0xf, true));   // wave_shr:1 (no "old" operand to initialise:
+            float hi = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own0[i]), 0x130, 0xf, 0xf, true));   // wave_shl:1  lanes 0 / 63 are edge lanes, overridden below)
             // a neighbour's value stands for an out-of-map column only at the ends of a row of tiles (the lane below / above
             // then belongs to another row): zero there; everything a lane loaded itself is already zero outside the map
             if (edge_lo) lo = oute[i];
