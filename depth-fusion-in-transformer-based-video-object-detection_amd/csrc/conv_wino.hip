@@ -217,7 +217,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
     auto store_v = [&](int buf) {
         if (!xloader) return;
         // the patch: [left neighbour's x0' + d | own x0 | own x0 + d | right neighbour's x0'']
-        float xr[16];
+        // (packed fp32 adds - v_pk_add_f32, two sums per vector instruction - for B^T d B: the rows of the patch are held as
+        // column pairs, stage 1 works on whole pairs, stage 2 gets (out0, out3) = pair0 - pair1 in one instruction)
+        using f2 = __attribute__((ext_vector_type(2))) float;
+        f2 pa[4], pb[4];                                           // row i: (col 0, col 1), (col 2, col 3)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float lo = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own1[i]), 0x138, 0xf, 0xf, true));   // wave_shr:1 (no "old" operand to initialise:
@@ -226,28 +229,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             // then belongs to another row): zero there; everything a lane loaded itself is already zero outside the map
             if (edge_lo) lo = oute[i];
             if (edge_hi) hi = oute[i];
-            xr[i * 4 + 0] = col0 ? lo : 0.f;
-            xr[i * 4 + 1] = own0[i];
-            xr[i * 4 + 2] = own1[i];
-            xr[i * 4 + 3] = col3 ? hi : 0.f;
+            pa[i] = (f2){col0 ? lo : 0.f, own0[i]};
+            pb[i] = (f2){own1[i], col3 ? hi : 0.f};
         }
-        // B^T d B
-        float tm[16];
-        const float *dd = xr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tm[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
-            tm[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
-            tm[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
-            tm[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
-        }
+        // B^T d (rows), both column pairs at once
+        const f2 ta[4] = {pa[0] - pa[2], pa[1] + pa[2], pa[2] - pa[1], pa[1] - pa[3]};
+        const f2 tb[4] = {pb[0] - pb[2], pb[1] + pb[2], pb[2] - pb[1], pb[1] - pb[3]};
         float *vs = Vs + buf * VCH + cil * TW + tl;               // [pos][ci][tile]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            vs[(i * 4 + 0) * (kCK * TW)] = tm[i * 4 + 0] - tm[i * 4 + 2];
-            vs[(i * 4 + 1) * (kCK * TW)] = tm[i * 4 + 1] + tm[i * 4 + 2];
-            vs[(i * 4 + 2) * (kCK * TW)] = tm[i * 4 + 2] - tm[i * 4 + 1];
-            vs[(i * 4 + 3) * (kCK * TW)] = tm[i * 4 + 1] - tm[i * 4 + 3];
+            const f2 o03 = ta[i] - tb[i];                         // (t0 - t2, t1 - t3)
+            vs[(i * 4 + 0) * (kCK * TW)] = o03.x;
+            vs[(i * 4 + 1) * (kCK * TW)] = ta[i].y + tb[i].x;
+            vs[(i * 4 + 2) * (kCK * TW)] = tb[i].x - ta[i].y;    // (as a packed add this pair costs a swizzle and a negation: more instructions)
+            vs[(i * 4 + 3) * (kCK * TW)] = o03.y;
         }
     };
 
