@@ -68,7 +68,7 @@ torch.backends.cudnn.allow_tf32 = False
 MSDA_TRAFFIC_PER_FRAME = (2 * 96670.5 + 134400.0) * 1024 / 32
 # fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
 # family's launches per step, from the PMC passes over this workload committed in profiles/r03_pmc_traffic.md
-FAMILY_TRAFFIC_PER_STEP = {"gemm": (98958.9e6, 204), "wino": (18937.7e6, 28), "igemm": (33215.5e6, 9)}
+FAMILY_TRAFFIC_PER_STEP = {"gemm": (98964.8e6, 204), "wino": (18930.5e6, 28), "igemm": (33212.0e6, 9)}
 
 # per-frame algorithmic work of config E in all-current mode and the one-pass bytes of the kernel families: generated by
 # tools/algorithmic_work.py (a walk over the built model at 800x1333) into tools/algorithmic_work.json; BASELINE.md
