@@ -52,14 +52,17 @@ __global__ __launch_bounds__(64 * WAVES * GROUPS) void mha_fwd(const float *__re
     const int col = lane & 31, half = lane >> 5;
     const int hd = blockIdx.y, b = blockIdx.z;
     const int qi = (blockIdx.x * WAVES + wave) * 32 + col;            // this lane's query
-    // B operand of the first product: Q[query][16*half .. +15], pre-scaled
+    // B operand of the first product: Q[query][16*half .. +15], pre-scaled by scale * log2(e): the scores are kept in the log2
+    // domain so that the softmax numerators are one v_exp_f32 each (softmax is invariant under the change of base; one multiply
+    // per score less - the attention's vector instructions run on the lanes its MFMAs need)
+    const float qs = scale * 1.44269504088896340736f;
     float qv[16];
     {
         const float *qp = q + b * q_batch + (long)min(qi, Lq - 1) * q_row + hd * D + half * 16;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 t = *reinterpret_cast<const float4 *>(qp + c * 4);
-            qv[c * 4 + 0] = t.x * scale; qv[c * 4 + 1] = t.y * scale; qv[c * 4 + 2] = t.z * scale; qv[c * 4 + 3] = t.w * scale;
+            qv[c * 4 + 0] = t.x * qs; qv[c * 4 + 1] = t.y * qs; qv[c * 4 + 2] = t.z * qs; qv[c * 4 + 3] = t.w * qs;
         }
     }
     f32x16 o;
@@ -96,21 +99,22 @@ __global__ __launch_bounds__(64 * WAVES * GROUPS) void mha_fwd(const float *__re
 #pragma unroll
         for (int t = 0; t < 16; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qv[t], s, 0, 0, 0);
         // ---- online softmax over this tile's keys, per query (= lanes l and l^32 together) ----
-        float tmax = -INFINITY;
+        if (j0 + TK > Lk) {                                            // (scalar: only the last tile has keys to mask)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= Lk) s[r] = -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+            for (int r = 0; r < 16; ++r)
+                if (j0 + (r & 3) + 8 * (r >> 2) + 4 * half >= Lk) s[r] = -INFINITY;
         }
+        float tmax = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mn = fmaxf(m, tmax);
-        const float resc = __expf(m - mn);                             // 0 on the first tile
+        const float resc = __builtin_amdgcn_exp2f(m - mn);             // 0 on the first tile
         m = mn;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - mn);                                  // p; exp(-inf) = 0 for padded keys
+            s[r] = __builtin_amdgcn_exp2f(s[r] - mn);                  // p; 2^(-inf) = 0 for padded keys
             psum += s[r];
             o[r] *= resc;
         }
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(64 * WAVES * GROUPS) void mha_fwd(const float *__re
             const float *p = smem + ((gq - 1) * WAVES + wave) * 18 * 64 + lane;
             const float mg = p[16 * 64], lg = p[17 * 64];
             const float mn = fmaxf(m, mg);                             // m is finite: group 0 owns tile 0
-            const float a = __expf(m - mn), bq = __expf(mg - mn);      // bq = 0 for a group that saw no key (m_g = -inf)
+            const float a = __builtin_amdgcn_exp2f(m - mn), bq = __builtin_amdgcn_exp2f(mg - mn);      // bq = 0 for a group that saw no key (m_g = -inf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = o[r] * a + p[r * 64] * bq;
             l = l * a + lg * bq;
