@@ -434,7 +434,6 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
                 unsigned char mk[HAS_MASK ? NIT : 1];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int D = BAL ? ((it * RS) / (32 * TP1)) * TM + p * TP1 * 32 + (it * RS) % (32 * TP1) : p * PR + it * RS;
                     if (HAS_R && !r_pre)
                         rr[HAS_R ? it : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, rbase_off + (unsigned)D * (unsigned)g.ldr * 4u, 0, 0));
