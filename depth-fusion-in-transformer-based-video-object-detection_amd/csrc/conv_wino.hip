@@ -204,7 +204,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
         const unsigned xs = (unsigned)ch * (unsigned)(kCK * HW) * 4u;             // scalar offset
         if (xloader) {
             // (two dword loads also for d = 1, where the columns are adjacent: hipcc of ROCm 7.2 lowers
-            // __builtin_amdgcn_raw_buffer_load_b64 to a single buffer_load_dword - the upper half is never loaded)
+            // __builtin_amdgcn_raw_buffer_load_b64 to a single buffer_load_dword - the upper half is never loaded.  The
+            // instruction written out as inline asm - buffer_load_dwordx2 into register pairs, an explicit s_waitcnt naming them
+            // in store_v - gave correct results and a K loop 15-27 % SLOWER: the compiler brackets every asm load with
+            // s_waitcnt for its own pending loads, 30 instead of 11 per iteration, and copies the pairs between the two code
+            // paths; round 3, dropped)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 own0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0[i], xs, 0));
