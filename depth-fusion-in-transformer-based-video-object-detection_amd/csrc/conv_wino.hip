@@ -208,7 +208,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs g)
             // instruction written out as inline asm - buffer_load_dwordx2 into register pairs, an explicit s_waitcnt naming them
             // in store_v - gave correct results and a K loop 15-27 % SLOWER: the compiler brackets every asm load with
             // s_waitcnt for its own pending loads, 30 instead of 11 per iteration, and copies the pairs between the two code
-            // paths; round 3, dropped)
+            // paths; round 3, dropped.  One 12 / 16-byte load per row at x0 for both own columns - builtins only, 8 instead of 12
+            // vector-memory instructions per chunk - was 8-14 % slower as well: a wide load occupies the address unit in
+            // proportion to its bytes per lane, the count of instructions is not what the memory pipe charges)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 own0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo0[i], xs, 0));
