@@ -271,6 +271,9 @@ _GEMM_MAX_BYTES = 1 << 31          # tests lower it to exercise the row-range pa
 # the 128 x 128 tile and leaves 19 workgroups for the 1200-row Linears of a 4-frame block: spatial stage 16.80 -> 16.97 ms with
 # it on the 134 400-row Linears only, 16.7 -> 17.3 ms on all of them, the 4-frame rank step 16.65 -> 18.9 ms).  DFX_LINEAR_LN=1
 # turns it on for A/B runs; the callers' ``norm=`` plumbing then costs nothing when it is off.
+# (A/B of round 3: the residual in the GEMM epilogue instead of in the LayerNorm pass moves 0.06 ms of 15.5 in the spatial stage -
+# inside the noise; off)
+_RESIDUAL_IN_GEMM = os.environ.get("DFX_LN_RESIDUAL_IN_GEMM", "0") == "1"
 _FUSE_LN = os.environ.get("DFX_LINEAR_LN", "0") == "1"
 _FUSE_LN_MIN_ROWS = int(os.environ.get("DFX_LINEAR_LN_MIN_ROWS", "32768"))
 
@@ -338,7 +341,9 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
     code = ACT[act] if act is not None else int(bool(relu))
     if norm is not None and (not _FUSE_LN or M < _FUSE_LN_MIN_ROWS):       # the LayerNorm as its own pass
-        if code and not act_first:
+        if (code and not act_first) or (not code and _RESIDUAL_IN_GEMM):
+            # the residual rides in the GEMM's epilogue (prefetched while the tile crosses LDS): the LayerNorm pass then reads one
+            # tensor instead of two.  Same sum, same order: (x W^T + b) + residual
             y = linear(x, weight, bias, residual=residual, add=add, x_blocked=x_blocked, act=act, relu=relu)
             return add_layernorm(y, None, norm)
         y = linear(x, weight, bias, add=add, x_blocked=x_blocked, act=act, relu=relu)
