@@ -49,14 +49,18 @@ def _require(cond, msg):
 
 
 def _check_inputs(named):
+    # (messages are only formatted on failure: this runs for every launch of the path)
     for name, t in named:
-        _require(t.is_contiguous(), f"{name} tensor has to be contiguous")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
     for name, t in named:
         # the reference raises "Not implemented on the CPU" (ms_deform_attn.h:38,60)
-        _require(t.is_cuda, f"{name} must be a CUDA tensor (MSDA is not implemented on the CPU)")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor (MSDA is not implemented on the CPU)")
     dev = named[0][1].device
     for name, t in named:
-        _require(t.device == dev, f"{name} is on {t.device}, expected {dev}")
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
 
 
 def _dims(value, spatial_shapes, sampling_loc, im2col_step):
@@ -69,8 +73,32 @@ def _dims(value, spatial_shapes, sampling_loc, im2col_step):
     return N, S, M, D, L, Lq, P
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev):
+    """Raw handle of the current stream of `dev` (host time matters here: ~450 launches per 13 ms step of a 4-frame block)."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev):
+    """Context that makes `dev` the current device - a no-op object when it already is (one process per GPU: always)."""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
 
 
 def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
@@ -88,7 +116,7 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
              "sampling_loc / attn_weight smaller than N*Lq*M*L*P")
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = getattr(lib, "dfx_msda_forward_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), N, S, M, D, L, Lq, P,
                 out.data_ptr(), _stream(value.device))
@@ -111,7 +139,7 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_loc = torch.zeros_like(sampling_loc)
     grad_aw = torch.zeros_like(attn_weight)
     fn = getattr(lib, "dfx_msda_backward_" + _SUFFIX[value.dtype])
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                 N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr(),
@@ -155,7 +183,7 @@ def msda_fused_forward(value, spatial_shapes, level_start_index, reference_point
     level = (USE_LEVEL_KERNEL and LEVEL_ON_REFERENCE_LAYOUTS and host is not None and L == 1 and Lr == 1 and M == 8 and D == 32
              and P == 4 and S == host[0][0] * host[0][1] and Lq >= LEVEL_MIN_QUERIES
              and lib.dfx_msda_fused_level_fits(host[0][0], host[0][1]))
-    with torch.cuda.device(value.device):
+    with _on(value.device):
         if level:  # the whole level lives in LDS
             import ctypes
             ly = _lib.LevelLayout(S * 256, 256, 32, 8, 4, 3 * mlp, 8, 3 * mlp, 4, 256, 32, 8, 4)   # reference layouts
@@ -204,7 +232,7 @@ def msda_level_forward(value_blk, reference_points, qproj_blk, N, H, W):
     base = qproj_blk.data_ptr()
     ns, nq = N * S, N * Lq
     ly = _lib.LevelLayout(S * 4, 4, 32 * ns, 8 * ns, 4 * ns, 12, 12 * nq, 12, 12 * nq, 4, 32 * nq, 8 * nq, 4 * nq)
-    with torch.cuda.device(value_blk.device):
+    with _on(value_blk.device):
         rc = lib.dfx_msda_fused_level_forward_f32(
             value_blk.data_ptr(), reference_points.data_ptr(), ref_dim, base, base + 32, ctypes.byref(ly),
             N, H, W, Lq, out.data_ptr(), _stream(value_blk.device))
@@ -234,7 +262,7 @@ def roi_align(inp, rois, output_size, spatial_scale, sampling_ratio, aligned=Tru
         N, C, H, W = inp.shape
         out = torch.empty((K, C, ph, pw), dtype=inp.dtype, device=inp.device)
         fn = lib.dfx_roi_align_nchw_f32
-    with torch.cuda.device(inp.device):
+    with _on(inp.device):
         rc = fn(inp.data_ptr(), rois.data_ptr(), N, C, H, W, K, ph, pw, float(spatial_scale),
                 int(sampling_ratio), int(bool(aligned)), out.data_ptr(), _stream(inp.device))
     _lib.check(rc, "roi_align")
@@ -254,7 +282,7 @@ def bias_act_(x, bias, residual=None, relu=True):
     if residual is not None:
         _require(residual.shape == x.shape and residual.dtype == x.dtype, "residual must match x")
     hw = x.numel() // max(N * C, 1)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.dfx_bias_act_nchw_f32(x.data_ptr(), bias.data_ptr(), 0 if residual is None else residual.data_ptr(),
                                        x.data_ptr(), N, C, hw, int(bool(relu)), _stream(x.device))
     _lib.check(rc, "bias_act_")
@@ -352,14 +380,14 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         _require(N == 256 and row_mask is None and not col_block and norm.weight.numel() == 256 and norm.weight.is_cuda,
                  "linear(norm=...): a LayerNorm over exactly 256 output columns, no row_mask / col_block")
         _require(M * K * 4 < _GEMM_MAX_BYTES, "linear(norm=...): operand of 2 GiB or more")
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = lib.dfx_linear_ln_f32(x2.data_ptr(), _ptr(add), K, M * 4 if x_blocked else 0, weight.data_ptr(), K, _ptr(bias),
                                        _ptr(residual), N, norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
                                        out.data_ptr(), N, M, K, code, int(bool(act_first)), _stream(x.device))
         _lib.check(rc, "linear + LayerNorm")
         return out
     splits = _split_k(M, N, K) if (add is None and row_mask is None and not col_block and not x_blocked and N % 4 == 0) else 0
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if splits > 1:
             ws = torch.empty((splits, M, N), dtype=torch.float32, device=x.device)
             rc = lib.dfx_gemm_splitk_f32(x2.data_ptr(), K, weight.data_ptr(), K, 0, _ptr(bias), 0, _ptr(residual), N,
@@ -403,7 +431,7 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     out = torch.empty((Nb, Co, H, W), dtype=x.dtype, device=x.device)
     if residual is not None:
         _require(residual.shape == out.shape, "residual must match the output")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.dfx_gemm_f32(w2.data_ptr(), 0, Ci, 0, x.data_ptr(), HW, Ci * HW, 1, _ptr(bias), 1,
                               _ptr(residual), HW, Co * HW, 0, 0, out.data_ptr(), HW, Co * HW, Co, HW, Ci, Nb,
                               int(bool(relu)), 0, 0, 0, _stream(x.device))
@@ -423,7 +451,7 @@ def conv1x1_pair(x1, x2, weight, bias=None, relu=False):
     _require(x1.dtype == torch.float32 and x2.shape == (Nb, K2, H, W) and weight.shape == (Co, K1 + K2),
              "conv1x1_pair: x1 [N,K1,H,W], x2 [N,K2,H,W], weight [Co,K1+K2], fp32")
     out = torch.empty((Nb, Co, H, W), dtype=x1.dtype, device=x1.device)
-    with torch.cuda.device(x1.device):
+    with _on(x1.device):
         rc = lib.dfx_conv1x1_pair_f32(weight.data_ptr(), x1.data_ptr(), K1 * H * W, K1, x2.data_ptr(), K2 * H * W, K2,
                                       _ptr(bias), out.data_ptr(), Co * H * W, Co, H * W, Nb, int(bool(relu)),
                                       _stream(x1.device))
@@ -444,7 +472,7 @@ def dynamic_conv(feats, params, norm1, norm2):
              "dynamic_conv: params must be [K, 2*C*dd] fp32 with contiguous rows")
     _require(norm2.normalized_shape[0] == C and norm1.eps == norm2.eps, "dynamic_conv: norm shapes / eps")
     out = torch.empty_like(feats)
-    with torch.cuda.device(feats.device):
+    with _on(feats.device):
         rc = lib.dfx_dynamic_conv_f32(feats.data_ptr(), params.data_ptr(), params.stride(0), norm1.weight.data_ptr(),
                                       norm1.bias.data_ptr(), norm2.weight.data_ptr(), norm2.bias.data_ptr(),
                                       out.data_ptr(), K, R, C, dd, float(norm1.eps), _stream(feats.device))
@@ -465,7 +493,7 @@ def mha(q, k, v, heads, scale):
     Lk = k.shape[1]
     _require(k.shape == (B, Lk, E) and v.shape == (B, Lk, E), "mha: k and v must be [B,Lk,E]")
     out = torch.empty((B, Lq, E), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         rc = lib.dfx_mha_f32(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
                              v.data_ptr(), v.stride(0), v.stride(1), out.data_ptr(), Lq * E, E, B, heads, Lq, Lk,
                              float(scale), _stream(q.device))
@@ -484,7 +512,7 @@ def box_refine(delta, reference, eps=1e-5):
              and delta.dtype == torch.float32 and reference.dtype == torch.float32,
              "box_refine: delta [...,4], reference [...,2|4], fp32")
     out = torch.empty_like(delta)
-    with torch.cuda.device(delta.device):
+    with _on(delta.device):
         rc = lib.dfx_box_refine_f32(delta.data_ptr(), reference.data_ptr(), rd, out.data_ptr(), delta.numel() // 4,
                                     float(eps), _stream(delta.device))
     _lib.check(rc, "box_refine")
@@ -505,7 +533,7 @@ def add_layernorm(x, residual, norm):
     _check_inputs(named)
     _require(x2.dtype == torch.float32 and norm.weight.numel() == C, "add_layernorm: fp32, LayerNorm over the last dim")
     out = torch.empty_like(x2)
-    with torch.cuda.device(x2.device):
+    with _on(x2.device):
         rc = lib.dfx_add_layernorm_f32(x2.data_ptr(), _ptr(residual), norm.weight.data_ptr(), norm.bias.data_ptr(),
                                        out.data_ptr(), x2.numel() // C, C, float(norm.eps), _stream(x2.device))
     _lib.check(rc, "add_layernorm")
@@ -520,7 +548,7 @@ def bias_relu_maxpool(x, bias):
     _require(x.dtype == torch.float32 and x.dim() == 4 and bias.numel() == x.shape[1], "bias_relu_maxpool: fp32 NCHW")
     N, C, H, W = x.shape
     out = torch.empty((N, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.dfx_bias_relu_maxpool_f32(x.data_ptr(), bias.data_ptr(), out.data_ptr(), N, C, H, W, _stream(x.device))
     _lib.check(rc, "bias_relu_maxpool")
     return out
@@ -558,7 +586,7 @@ class ConvPlan:
         if self.algo == "wino":
             self.u = torch.empty(16 * Co * Ci, dtype=torch.float32, device=w.device)
             sc = None if scale is None else scale.detach().float().contiguous()
-            with torch.cuda.device(w.device):
+            with _on(w.device):
                 rc = lib.dfx_wino_weights_f32(w.data_ptr(), _ptr(sc), self.u.data_ptr(), Co, Ci, _stream(w.device))
             _lib.check(rc, "wino_weights")
         else:
@@ -603,7 +631,7 @@ class ConvPlan:
         step = N
         if self.algo == "wino" and N * self.Ci * H * W >= self.WINO_MAX_ELEMENTS:
             step = max(1, (self.WINO_MAX_ELEMENTS - 1) // (self.Ci * H * W))
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             for n0 in range(0, N, step):
                 n1 = min(N, n0 + step)
                 xs, ys = x[n0:n1], y[n0:n1]
@@ -630,7 +658,7 @@ def group_norm(x, norm, tokens_out=False):
     N, C, H, W = x.shape
     stats = torch.empty(N * norm.num_groups * 2, dtype=torch.float32, device=x.device)
     y = torch.empty((N, H * W, C) if tokens_out else (N, C, H, W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.dfx_group_norm_f32(x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), stats.data_ptr(),
                                     y.data_ptr(), N, C, H * W, norm.num_groups, float(norm.eps), int(bool(tokens_out)),
                                     _stream(x.device))
