@@ -921,6 +921,10 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     // every CU 8 tiles, 4-5 % ahead of 64 x 64 / 64 x 128 there (profiles/r03_gemm_tiles_F4_F8.txt)
     if (b_is_kn && M % 128 == 0 && K >= 512 && g.splits <= 1 && (long)(M / 128) * ((N + 63) / 64) * zb >= 2048)
         return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
+    // the decoder's first FFN Linear at 32 frames (9600 x 1024 x 256): 1200 tiles of 128 x 64 are 10 % ahead of 64 x 128 / 64 x 64
+    // (tools/bench_gemm_queries.py, tools/r03_exp19.sh: 55.6 vs 61.2 / 57.2 us)
+    if (!b_is_kn && M % 128 == 0 && N >= 1024 && K <= 256 && g.splits <= 1 && (long)(M / 128) * ((N + 63) / 64) * zb >= 1024)
+        return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
     if (t128 < 8 * 256 && 0.95 * fill(t64) > fill(t128)) return launch<64, 64, 2, 2>(g, batch, b_is_kn, st);
     return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
 }
