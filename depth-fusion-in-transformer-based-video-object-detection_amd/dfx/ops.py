@@ -306,11 +306,15 @@ _FUSE_LN = os.environ.get("DFX_LINEAR_LN", "0") == "1"
 _FUSE_LN_MIN_ROWS = int(os.environ.get("DFX_LINEAR_LN_MIN_ROWS", "32768"))
 
 
+_SPLITK_MIN_K = int(os.environ.get("DFX_SPLITK_MIN_K", "2048"))      # (A/B aids)
+_SPLITK_RANGE = int(os.environ.get("DFX_SPLITK_RANGE", "512"))
+
+
 def _split_k(M, N, K):
     """Number of K ranges for a GEMM with few output tiles and a long K (0 = no split): as many as keep the
     128 x 128 (or 64 x 128 for small M) tiles x ranges within one resident round of workgroups (3 per CU for the
     large tile, 4 for the small one), at least 32 K-steps per range."""
-    if K < 2048:
+    if K < _SPLITK_MIN_K:
         return 0
     if M >= 128 and N >= 128:
         tiles, slots = -(-M // 128) * -(-N // 128), 768
@@ -318,7 +322,7 @@ def _split_k(M, N, K):
         tiles, slots = -(-M // 64) * -(-N // 128), 1024
     if tiles * 2 > slots:
         return 0
-    return max(1, min(K // 512, slots // tiles))
+    return max(1, min(K // _SPLITK_RANGE, slots // tiles))
 
 
 def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=None, col_block=0, x_blocked=False,
