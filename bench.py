@@ -1,6 +1,6 @@
 """Headline benchmark: frames/s of TransVOD++ Late-Fusion inference at 800x1333 RGB-D on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -225,6 +225,24 @@ def cpu_baseline(height, width, threads, frames=32, warm_frames=2):
     return line
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (one per GPU) through
+    torch.distributed.run with the arguments of this call, as the reference's own launcher forks its ranks
+    (/root/reference/tools/launch.py:159-192).  The children inherit stdout, so rank 0's JSON line is this command's
+    output; -> the launcher's return code.  Called before this process has touched the GPU; it never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,11 +278,13 @@ def main():
                     help="(no-op since round 2: no library convolution is left in the path)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))       # no GPU call has happened in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the operators have no CPU path)")
     if a.backend != "nccl":                       # rehearsal: several ranks may share one GPU
@@ -445,6 +465,8 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "ms_per_step_p50": round(step_ms[len(step_ms) // 2], 3),
             "higher_is_better": True, "scaling": "strong" if clips == 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl": {"backend": dist.get_backend() if world > 1 else None,
+                     "world": dist.get_world_size() if world > 1 else 1},
             "config": {"workload": f"TransVOD++ LateFusion, {a.frames}-frame {a.height}x{a.width} RGB-D clip, "
                                    f"all-current mode (R={a.frames - 1}), L=1 DC5 (S={-(-a.height // 16) * -(-a.width // 16)}), 300 queries, 3 classes",
                        "clips_per_step": clips, "frames_per_gpu": rank_frames, "frames_per_gpu_per_clip": per_rank,

@@ -126,27 +126,35 @@ def test_clip_pipeline_submit_matches_call():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("clips_per_step,pipeline", [(None, 1), (0, 1), (1, 0)])
-def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline):
+@pytest.mark.parametrize("clips_per_step,pipeline,launcher", [(None, 1, False), (0, 1, True), (1, 0, True)])
+def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline, launcher):
     """bench.py's own N > 1 code path (rank / world from the environment, frame sharding, barrier, MAX over ranks,
     rank 0 prints the line) with two ranks sharing this GPU over gloo - a rehearsal of the driver's RCCL launch on a
     small clip.  The line must parse and describe a 2-rank run: by default ONE clip in flight sharded over the ranks
     (BASELINE.json's configuration, strong scaling) plus the N-clips-per-step throughput figure as an extra key;
     --clips-per-step 0 makes the throughput mode the measured one (weak scaling); by default the exchange sits on the
-    side stream of the clip pipeline (ClipRunner.submit), --pipeline 0 runs one clip at a time on one stream."""
+    side stream of the clip pipeline (ClipRunner.submit), --pipeline 0 runs one clip at a time on one stream.
+    ``launcher=False`` is the driver's N = 1 command form with N changed - plain ``python bench.py --gpus 2`` - which must
+    start its two ranks by itself (bench.py:launch_ranks) and give the same line."""
     import json
     import subprocess
     port = 29700 + (os.getpid() + 7 * (clips_per_step or 3) + 13 * pipeline) % 2000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4",
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4",
            "--height", "128", "--width", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pipeline", str(pipeline)]
     if clips_per_step is not None:
         cmd += ["--clips-per-step", str(clips_per_step)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["rccl"] == {"backend": "gloo", "world": 2}
     assert line["config"]["frames_per_gpu_per_clip"] == 2 and line["roofline"]["bound"] == "mfma"
     assert line["config"]["clip_pipeline"] == (pipeline >= 1)
     if clips_per_step == 0:
