@@ -449,8 +449,7 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // the phase shift between SIMD partners pays with many chunks (layer3 / layer4: 1.5 % faster with it, A/B of round 3);
     // with 8 chunks (layer1, Ci = 64) the kernel is 1.4 % faster without it
     // (s_setprio 1 for waves 4-7, the static-priority recipe of the bf16 attention loops: 4-5 % SLOWER here, round 3)
-    static const char *np_env = getenv("DFX_WINO_NO_PHASE");
-    g.no_phase = np_env ? np_env[0] == '1' : g.nchunk <= 8;
+    g.no_phase = dfx::tuning().wino_no_phase >= 0 ? dfx::tuning().wino_no_phase == 1 : g.nchunk <= 8;
     g.xbytes = (unsigned)((long)N * Ci * H * W * 4);
     g.ubytes = (unsigned)((long)16 * Co * Ci * 4);
     const long ntb = (g.tiles + kTB - 1) / kTB;
@@ -462,7 +461,7 @@ extern "C" int dfx_conv3x3_wino_f32(const float *x, const float *u, const float 
     // at most ~60 % of the CUs is run as quarter-size workgroups instead (4 per block: ~0.3 of a round when they fit
     // the chip at once); a problem smaller than one round is all quarter-size.
     const long rem = blocks % 256, full = blocks - rem;
-    const bool quarter_tail = rem > 0 && rem <= 160 && !getenv("DFX_WINO_NO_TAIL");
+    const bool quarter_tail = rem > 0 && rem <= 160 && !dfx::tuning().wino_no_tail;
     const long main_blocks = quarter_tail ? full : blocks;
     const long flops_per_block = 2L * 16 * kCoB * Ci * kTB;
     // measurement aid (dfx_profile_*): MFMA flops the launch executes (16 products per 2x2 output tile, padded tiles

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
@@ -49,6 +50,51 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk)
 }
 
 constexpr int kWave = 64;
+
+// ---- tuning / diagnostic knobs ----------------------------------------------------------------
+// Every DFX_* environment switch of the launchers (INTEGRATION.md "Diagnostic environment variables"), read ONCE per
+// process - a launch costs no getenv() scan and never races a setenv() - and again only on dfx_tuning_reload()
+// (dfx.ops.reload_tuning(): what a test or an A/B tool calls after it changed the environment).
+struct Tuning {
+    int gemm_group = 8;              // DFX_GEMM_GROUP: tile rows per XCD walk
+    int gemm_tile = -1;              // DFX_GEMM_TILE: forced tile (0..7), -1 = the rules
+    int gemm_rows_max = 4800;        // DFX_GEMM_ROWS_MAX / DFX_GEMM_NO_ROWS (-> 0): row limit of linear_rows_kernel
+    bool gemm_old_epilogue = false;  // DFX_GEMM_OLD_EPILOGUE
+    bool gemm_no_dma = false;        // DFX_GEMM_NO_DMA
+    bool gemm_narrow_epilogue = false;  // DFX_GEMM_NARROW_EPILOGUE
+    bool gemm_no_deep = false;       // DFX_GEMM_NO_DEEP
+    int mha_groups = 0;              // DFX_MHA_GROUPS: 1 / 2 / 4 forced, 0 = the rule
+    int wino_no_phase = -1;          // DFX_WINO_NO_PHASE: 0 / 1 forced, -1 = the rule
+    bool wino_no_tail = false;       // DFX_WINO_NO_TAIL
+    bool level_not_persistent = false;  // DFX_LEVEL_NOT_PERSISTENT
+    bool level_variant_set = false;  // DFX_LEVEL_VARIANT given
+    int level_variant = 0;           // DFX_LEVEL_VARIANT: kernel variant of msda_level.hip (A/B)
+    void read()
+    {
+        *this = Tuning();
+        auto num = [](const char *n, int dflt) { const char *e = getenv(n); return e ? atoi(e) : dflt; };
+        auto flag = [](const char *n) { return getenv(n) != nullptr; };
+        gemm_group = num("DFX_GEMM_GROUP", 8);
+        if (const char *e = getenv("DFX_GEMM_TILE")) gemm_tile = e[0] >= '0' && e[0] <= '9' ? e[0] - '0' : -1;
+        gemm_rows_max = flag("DFX_GEMM_NO_ROWS") ? 0 : num("DFX_GEMM_ROWS_MAX", 4800);
+        gemm_old_epilogue = flag("DFX_GEMM_OLD_EPILOGUE");
+        gemm_no_dma = flag("DFX_GEMM_NO_DMA");
+        gemm_narrow_epilogue = flag("DFX_GEMM_NARROW_EPILOGUE");
+        gemm_no_deep = flag("DFX_GEMM_NO_DEEP");
+        if (const char *e = getenv("DFX_MHA_GROUPS")) mha_groups = e[0] == '4' ? 4 : e[0] == '2' ? 2 : 1;
+        if (const char *e = getenv("DFX_WINO_NO_PHASE")) wino_no_phase = e[0] == '1';
+        wino_no_tail = flag("DFX_WINO_NO_TAIL");
+        level_not_persistent = flag("DFX_LEVEL_NOT_PERSISTENT");
+        level_variant_set = flag("DFX_LEVEL_VARIANT");
+        level_variant = num("DFX_LEVEL_VARIANT", 0);
+    }
+};
+inline Tuning &tuning_slot()
+{
+    static Tuning t = [] { Tuning x; x.read(); return x; }();
+    return t;
+}
+inline const Tuning &tuning() { return tuning_slot(); }
 
 // ---- optional per-launch timing -----------------------------------------------------------
 // Measurement aid for bench.py (include/dfx_msda.h, dfx_profile_*).  While enabled, kernels launched

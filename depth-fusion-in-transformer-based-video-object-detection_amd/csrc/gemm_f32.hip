@@ -627,8 +627,7 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
 // 4 and 8 tie, 2.7 % less time over the path's shapes than the dispatch order (layer4 shortcut 4 %, layer2 conv3 6 %).
 int tile_group(const Args &g, int batch)
 {
-    if (const char *e = getenv("DFX_GEMM_GROUP")) return atoi(e);
-    return 8;
+    return dfx::tuning().gemm_group;
 }
 
 template <int BM, int BN, int WM, int WN, int BK = 16>
@@ -642,10 +641,10 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     g.group_m = tile_group(g, batch);
     g.fast_cblk = g.cblk > 0 && g.cblk % 4 == 0 && BN % g.cblk == 0 && g.N % g.cblk == 0 && !g.R && g.relu != 2 && !g.ln_g &&
                   (!g.bias || g.bias_per_row || dfx::aligned16(g.bias)) && dfx::aligned16(g.C) && (g.cblk_stride & 3) == 0 && (g.strideC & 3) == 0 &&
-                  ((long)(g.N / g.cblk) * g.cblk_stride) * 4 < (1L << 31) && !getenv("DFX_GEMM_OLD_EPILOGUE");
+                  ((long)(g.N / g.cblk) * g.cblk_stride) * 4 < (1L << 31) && !dfx::tuning().gemm_old_epilogue;
     // (row offsets of a tile reach up to BM rows past M before the hardware range check drops them: they must not wrap)
     g.fast_epi = g.wide_epilogue && !g.ln_g && !g.act_first && g.relu != 2 && ((long)(g.M + BM) * g.ldc + g.N) * 4 < (1L << 31) &&
-                 (!g.R || ((long)(g.M + BM) * g.ldr + g.N) * 4 < (1L << 31)) && !getenv("DFX_GEMM_OLD_EPILOGUE");
+                 (!g.R || ((long)(g.M + BM) * g.ldr + g.N) * 4 < (1L << 31)) && !dfx::tuning().gemm_old_epilogue;
     const dim3 grid((unsigned)total), block(64 * WM * WN);
     // measurement aid (dfx_profile_*): flops of the launch in the byte field, tag_a = -1 ([K,N] operand: 1x1 convolution)
     // or -2 (Linear), tag_b = tile
@@ -653,7 +652,7 @@ int launch(const Args &g_in, int batch, int b_is_kn, hipStream_t st)
     const int kloc = g.splits > 1 ? g.kper : g.K;
     // LDS-DMA staging unless the prologue add needs registers, K has a tail, or the kernel is the HBM-bound short-K
     // residual convolution (layer1 / layer2 conv3), where the DMA wait also drains the residual prefetch
-    bool dma = !g.A2 && g.K % BK == 0 && kloc % BK == 0 && !(g.R && kloc <= 128) && !getenv("DFX_GEMM_NO_DMA");
+    bool dma = !g.A2 && g.K % BK == 0 && kloc % BK == 0 && !(g.R && kloc <= 128) && !dfx::tuning().gemm_no_dma;
     if (g.B2) {
         if (g.A2 || g.K % BK || g.K1 % BK || g.splits > 1 || !b_is_kn)
             return dfx::fail(DFX_EINVAL, "gemm: a two-segment operand needs K and K1 multiples of %d, no A2, no split-K", BK);
@@ -752,8 +751,7 @@ __global__ __launch_bounds__(64 * NW) void linear_rows_kernel(const Args g)
 // few rows, [N,K] operand, plain row-major operands and epilogue: K = 64 * NW * CH
 bool rows_kernel_applies(const Args &g, int batch, int b_is_kn)
 {
-    static const char *mx = getenv("DFX_GEMM_ROWS_MAX");          // tuning aid: the row limit (0 = kernel off)
-    const int max_rows = getenv("DFX_GEMM_NO_ROWS") ? 0 : mx ? atoi(mx) : 4800;
+    const int max_rows = dfx::tuning().gemm_rows_max;          // tuning aid: the row limit (0 = kernel off)
     const int tiles_n = (g.N + 31) / 32;
     return !b_is_kn && batch == 1 && g.splits <= 1 && !g.mask && !g.cblk && !g.ablk_stride && !g.B2 && !g.ln_g &&
            !g.bias_per_row && (g.M <= max_rows || (max_rows > 0 && g.N <= 128)) && (g.N <= 32 || (g.N % 32 == 0 && g.wide_epilogue)) && g.N <= 1024 &&
@@ -803,7 +801,7 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         return dfx::fail(DFX_EINVAL, "gemm: K-block-major A needs a_block_stride >= 4 * M (a multiple of 4) and no A2");
     const int wide = c_block == 0 && (N & 3) == 0 && (ldc & 3) == 0 && (strideC & 3) == 0 && dfx::aligned16(C) &&
                      (!R || ((ldr & 3) == 0 && (strideR & 3) == 0 && dfx::aligned16(R))) &&
-                     (!bias || bias_per_row || dfx::aligned16(bias)) && !getenv("DFX_GEMM_NARROW_EPILOGUE");
+                     (!bias || bias_per_row || dfx::aligned16(bias)) && !dfx::tuning().gemm_narrow_epilogue;
     Args g{A, A2, lda, strideA, B, ldb, strideB, bias, bias_per_row, R, ldr, strideR, row_mask, strideMask, C, ldc, strideC,
            M, N, K, relu, c_block, c_block_stride, a_block_stride, wide, 1, K};
     return choose_and_launch(g, batch, b_is_kn, static_cast<hipStream_t>(stream));
@@ -869,7 +867,8 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     const long zb = (long)batch * (g.splits > 1 ? g.splits : 1);
     if (rows_kernel_applies(g, batch, b_is_kn)) return launch_rows(g, st);
     // tile choice.  Small M / N pick the matching narrow tile.
-    if (const char *force = getenv("DFX_GEMM_TILE")) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128
+    if (dfx::tuning().gemm_tile >= 0) {      // tuning aid: 0 = 128x128, 1 = 128x64, 2 = 64x128
+        const char force[1] = {(char)('0' + dfx::tuning().gemm_tile)};
         if (force[0] == '0') return launch<128, 128, 2, 2>(g, batch, b_is_kn, st);
         if (force[0] == '1') return launch<128, 64, 2, 2>(g, batch, b_is_kn, st);
         if (force[0] == '2') return launch<64, 128, 1, 4>(g, batch, b_is_kn, st);
@@ -916,7 +915,7 @@ int choose_and_launch(const Args &g, int batch, int b_is_kn, hipStream_t st)
     // At most one 64 x 64 workgroup per CU (the 300-query layers of a small rank block: M = 1200, N = 256): nothing hides
     // the global-load latency of a K-step but the step before it, so the K loop runs at ~1 us per step whatever its
     // depth; 64-deep steps quarter their number (profiles/r02_rank_step.txt).
-    if (t64 <= 320 && K >= 128 && !getenv("DFX_GEMM_NO_DEEP")) return launch<64, 64, 2, 2, 64>(g, batch, b_is_kn, st);
+    if (t64 <= 320 && K >= 128 && !dfx::tuning().gemm_no_deep) return launch<64, 64, 2, 2, 64>(g, batch, b_is_kn, st);
     // deep 1x1 convolutions of an 8-frame block (layer4 conv1 2048 -> 512, layer2 conv1 512 -> 128): 128 x 64 once it gives
     // every CU 8 tiles, 4-5 % ahead of 64 x 64 / 64 x 128 there (profiles/r03_gemm_tiles_F4_F8.txt)
     if (b_is_kn && M % 128 == 0 && K >= 512 && g.splits <= 1 && (long)(M / 128) * ((N + 63) / 64) * zb >= 2048)

@@ -181,7 +181,7 @@ extern "C" int dfx_mha_f32(const float *q, long q_batch, long q_row, const float
     // wave groups over the keys while the launch leaves CUs idle (see the head of the file); DFX_MHA_GROUPS=1/2/4 forces
     const long blocks = (long)grid.x * grid.y * grid.z;
     int groups = Lk >= 128 && blocks <= 400 ? 4 : Lk >= 128 && blocks <= 800 ? 2 : 1;
-    if (const char *f = getenv("DFX_MHA_GROUPS")) groups = f[0] == '4' ? 4 : f[0] == '2' ? 2 : 1;
+    if (dfx::tuning().mha_groups) groups = dfx::tuning().mha_groups;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (groups == 4)
         hipLaunchKernelGGL(mha_fwd<4>, grid, dim3(64 * WAVES * 4), 0, st, q, q_batch, q_row, k, k_batch, k_row, v, v_batch, v_row,

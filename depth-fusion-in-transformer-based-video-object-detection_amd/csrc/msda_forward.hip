@@ -354,3 +354,9 @@ extern "C" int dfx_profile_drain(float *ms, long *bytes, int *tag_a, int *tag_b,
 }
 
 extern "C" const char *dfx_last_error(void) { return dfx::err_slot(); }
+
+extern "C" int dfx_tuning_reload(void)
+{
+    dfx::tuning_slot().read();
+    return DFX_OK;
+}

@@ -344,7 +344,7 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         ncu = n / 8 * 8;
     }
-    const long grid = (blocks < ncu || getenv("DFX_LEVEL_NOT_PERSISTENT")) ? blocks : ncu;
+    const long grid = (blocks < ncu || dfx::tuning().level_not_persistent) ? blocks : ncu;
     // algorithmic bytes of this launch: value + (offsets, logits) + out, fp32
     const long bytes = 4L * ((long)N * S * 256 + 3L * N * Lq * 8 * 4 + (long)N * Lq * 256);
     if (ref_dim == 2)

@@ -3,7 +3,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdfx.so")
+# DFX_LIBRARY selects another build of the library (diagnostic / ablation builds of tools/ab.sh); it must exist - there is no
+# fall back to the shipped one
+_SO = os.environ.get("DFX_LIBRARY") or os.path.join(_HERE, "libdfx.so")
 _lib = None
 
 _i, _l, _p = ctypes.c_int, ctypes.c_long, ctypes.c_void_p
@@ -17,6 +19,7 @@ SIGNATURES = {
     "dfx_msda_backward_f64": [_p] * 6 + _DIMS + [_p, _p, _p, _p],
     "dfx_msda_fused_forward_f32": [_p, _p, _p, _p, _i, _i, _p, _l, _p, _l] + _DIMS + [_p, _p],
     "dfx_profile_enable": [_i],
+    "dfx_tuning_reload": [],
     "dfx_profile_drain": [_p, _p, _p, _p, _i],
     "dfx_msda_fused_level_fits": [_i, _i],
     "dfx_msda_fused_level_forward_f32": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],

@@ -30,6 +30,12 @@ def profile_start():
     _lib.load().dfx_profile_enable(1)
 
 
+def reload_tuning():
+    """The library reads its DFX_* environment switches once per process (csrc/dfx_common.h:Tuning); call this after
+    changing one of them in a running process (tests, A/B tools)."""
+    _lib.load().dfx_tuning_reload()
+
+
 def profile_stop(cap=65536):
     import ctypes
     lib = _lib.load()
@@ -372,6 +378,9 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         _require(row_mask.numel() == M, "row_mask must have one entry per row")
         row_mask = row_mask.reshape(-1).to(torch.uint8) if row_mask.dtype != torch.uint8 else row_mask.reshape(-1)
     code = ACT[act] if act is not None else int(bool(relu))
+    if norm is not None:      # one contract for both routes below (separate LayerNorm pass / LayerNorm in the GEMM epilogue)
+        _require(N == 256 and row_mask is None and not col_block and norm.weight.numel() == 256 and norm.weight.is_cuda,
+                 "linear(norm=...): a LayerNorm over exactly 256 output columns, no row_mask / col_block")
     if norm is not None and (not _FUSE_LN or M < _FUSE_LN_MIN_ROWS):       # the LayerNorm as its own pass
         if (code and not act_first) or (not code and _RESIDUAL_IN_GEMM):
             # the residual rides in the GEMM's epilogue (prefetched while the tile crosses LDS): the LayerNorm pass then reads one
@@ -381,8 +390,6 @@ def linear(x, weight, bias=None, relu=False, residual=None, add=None, row_mask=N
         y = linear(x, weight, bias, add=add, x_blocked=x_blocked, act=act, relu=relu)
         return add_layernorm(y, None if residual is None else residual.reshape(y.shape), norm)
     if norm is not None:
-        _require(N == 256 and row_mask is None and not col_block and norm.weight.numel() == 256 and norm.weight.is_cuda,
-                 "linear(norm=...): a LayerNorm over exactly 256 output columns, no row_mask / col_block")
         _require(M * K * 4 < _GEMM_MAX_BYTES, "linear(norm=...): operand of 2 GiB or more")
         with _on(x.device):
             rc = lib.dfx_linear_ln_f32(x2.data_ptr(), _ptr(add), K, M * 4 if x_blocked else 0, weight.data_ptr(), K, _ptr(bias),

@@ -37,15 +37,18 @@ from .fused import enable_fused_inference
 class ClipRunner:
     MIN_OVERLAP_BATCHES = 3
 
-    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True):
+    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True, gather_on_one_rank=False):
         """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode.
         fused: use the GPU-only fused inference routes (models/fused.py); default = model is on a GPU.
         overlap: on a GPU, run the backbones of micro-batch i+1 on one HIP stream while the transformer
         and the query/RoI fusion of micro-batch i (many short kernels that leave most CUs idle) run on
         another; results are identical, only the schedule changes.  Used when the block has at least
         MIN_OVERLAP_BATCHES micro-batches (measured, tools/rank_step.py: 4 micro-batches of 8 frames
-        143.3 -> 133.1 ms, 2 micro-batches 72.8 -> 74.1 ms)."""
+        143.3 -> 133.1 ms, 2 micro-batches 72.8 -> 74.1 ms).
+        gather_on_one_rank: run the collective of ``exchange`` although the group has one rank (RCCL's call path on a
+        one-GPU box); a one-rank group skips it otherwise."""
         self.model = model
+        self.gather_on_one_rank = gather_on_one_rank
         self.micro_batch = micro_batch
         self.group = group
         self.overlap = overlap
@@ -173,7 +176,7 @@ class ClipRunner:
         if not (dist.is_available() and dist.is_initialized()):
             return ref, logits
         world = dist.get_world_size(self.group)
-        if world == 1 and not getattr(self, "gather_on_one_rank", False):     # (set by a test: RCCL's call path with one rank)
+        if world == 1 and not self.gather_on_one_rank:
             return ref, logits
         BF, Q, C = ref.shape
         assert BF % clips == 0, "the rank's block must hold the same number of frames of every clip"
@@ -307,20 +310,47 @@ class VideoStream:
     def push(self, frames, mask=None, last=False):
         """frames [F,C,H,W]: this rank's block of the next world * F frames of the video; ``last``: the video ends with
         this block.  -> [(frame index, {"pred_logits" [Q,K], "pred_boxes" [Q,4]}), ...] for the rank's frames whose
-        outputs became computable, in frame order."""
+        outputs became computable, in frame order.
+        Every rank passes the SAME F on a call (frame ``seen + rank * F + i``; the all-gather carries equal blocks): a video
+        whose length is not a multiple of world * F ends with a push of fewer frames per rank - down to F = 1 - and, when
+        fewer than ``world`` frames are left, with the last of them repeated on the ranks that have none and ``pad`` = the
+        number of repeated frames (they are computed and dropped).  A differing F is caught here, before the collective."""
+        return self._push(frames, mask, last, 0)
+
+    @torch.no_grad()
+    def push_tail(self, frames, pad, mask=None):
+        """The video's last block when fewer than world * F frames are left: every rank still passes F frames, the final
+        ``pad`` frames of the world * F (rank-major) being repeats that are computed and dropped.  Ends the video."""
+        return self._push(frames, mask, True, int(pad))
+
+    def _push(self, frames, mask, last, pad):
         r = self.runner
         world = dist.get_world_size(r.group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(r.group) if world > 1 else 0
         F_ = frames.shape[0]
+        if world > 1:       # unequal blocks would hang or mis-index the gather: one tiny collective buys a clear error
+            sizes = torch.tensor([F_, pad], dtype=torch.long, device=frames.device if dist.get_backend(r.group) == "nccl" else "cpu")
+            lo, hi = sizes.clone(), sizes.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=r.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=r.group)
+            if not torch.equal(lo, hi):
+                raise ValueError(f"VideoStream.push: every rank must pass the same number of frames and the same pad "
+                                 f"(this rank: {F_}, {pad}; over the ranks: {lo.tolist()} .. {hi.tolist()})")
+        assert 0 <= pad < world * F_, "pad counts repeated frames at the end of the world * F block"
         local = r.frames_forward(frames, mask)
         all_ref, all_logits = r.exchange(local["ref"], local["logits"])
         base = self.seen
-        for j in range(world * F_):
+        real = world * F_ - pad
+        for j in range(real):
             self.bank[base + j] = (all_ref[j], all_logits[j])
         for i in range(F_):
-            self.pending[base + rank * F_ + i] = {k: local[k][i] for k in ("cur", "ref_last", "memory", "valid_ratios")}
+            if rank * F_ + i < real:
+                # (slices of a block are cloned when it holds several frames: a view would pin the whole block's memory
+                # tensor [F,S,C] until the first R frames' outputs are emitted)
+                self.pending[base + rank * F_ + i] = {k: (local[k][i].clone() if F_ > 1 else local[k][i])
+                                                     for k in ("cur", "ref_last", "memory", "valid_ratios")}
         self.meta = (local["spatial_shapes"], local["level_start_index"])
-        self.seen = base + world * F_
+        self.seen = base + real
         return self._emit(last)
 
     def _emit(self, ended):

@@ -33,3 +33,23 @@ class Linear(nn.Linear):
             from dfx import ops
             return ops.linear(x.contiguous(), self.weight, self.bias)
         return super().forward(x)
+
+
+def post_is_fusable(post):
+    """post = (residual, norm[, dropout]): may the add + LayerNorm ride in a GEMM epilogue?  Only when the sub-layer's
+    Dropout is the identity (eval mode or p = 0) - the reference applies ``norm(residual + dropout(out))``
+    (/root/reference/models/deformable_transformer_single.py:635-643) also under no_grad in train mode."""
+    if post is None:
+        return False
+    drop = post[2] if len(post) > 2 else None
+    return drop is None or not drop.training or drop.p == 0
+
+
+def apply_post(post, out):
+    """norm(residual + dropout(out)) for post = (residual, norm[, dropout]); ``out`` itself when post is None."""
+    if post is None:
+        return out
+    drop = post[2] if len(post) > 2 else None
+    if drop is not None:
+        out = drop(out)
+    return post[1](post[0] + out)

@@ -13,6 +13,8 @@ import torch
 
 from dfx import ops as _ops
 
+from .fused import apply_post, post_is_fusable
+
 
 def usable(mha, *tensors):
     """Inference on the GPU in fp32 with 32-wide heads and a packed in_proj: the fused route applies."""
@@ -31,7 +33,8 @@ def project_kv(mha, pool):
 def forward(mha, q_in, k_in, v_in, post=None, kv=None):
     """mha: nn.MultiheadAttention; q_in [B,Lq,E], k_in / v_in [B,Lk,E] -> [B,Lq,E]
     (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights).
-    post = (residual [B,Lq,E], norm): -> norm(residual + output), the add and the LayerNorm in out_proj's GEMM epilogue.
+    post = (residual [B,Lq,E], norm[, dropout]): -> norm(residual + dropout(output)), the add and the LayerNorm in out_proj's
+    GEMM epilogue when the dropout is the identity (eval mode).
     kv [B,Lk,2E]: already projected keys / values (``project_kv`` rows); k_in / v_in are then ignored."""
     E, H = mha.embed_dim, mha.num_heads
     W, b = mha.in_proj_weight, mha.in_proj_bias
@@ -39,10 +42,10 @@ def forward(mha, q_in, k_in, v_in, post=None, kv=None):
     if kv is not None:
         q = _ops.linear(q_in.contiguous(), W[:E], b[:E]).view(B, Lq, E)
         ctx = _ops.mha(q, kv[..., :E], kv[..., E:], H, 1.0 / math.sqrt(E // H))
-        if post is not None and E == 256:
+        if post_is_fusable(post) and E == 256:
             return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias, residual=post[0].contiguous(), norm=post[1])
         out = _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
-        return out if post is None else post[1](post[0] + out)
+        return apply_post(post, out)
     Lk = k_in.shape[1]
     same_qk, same_kv = q_in is k_in, k_in is v_in
     q_in, k_in, v_in = q_in.contiguous(), k_in.contiguous(), v_in.contiguous()
@@ -58,7 +61,7 @@ def forward(mha, q_in, k_in, v_in, post=None, kv=None):
         k = _ops.linear(k_in, W[E:2 * E], b[E:2 * E]).view(B, Lk, E)
         v = _ops.linear(v_in, W[2 * E:], b[2 * E:]).view(B, Lk, E)
     ctx = _ops.mha(q, k, v, H, 1.0 / math.sqrt(E // H))
-    if post is not None and E == 256:
+    if post_is_fusable(post) and E == 256:
         return _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias, residual=post[0].contiguous(), norm=post[1])
     out = _ops.linear(ctx, mha.out_proj.weight, mha.out_proj.bias)
-    return out if post is None else post[1](post[0] + out)
+    return apply_post(post, out)

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from models.fused import Linear
+from models.fused import Linear, apply_post, post_is_fusable
 
 from dfx import ops as _ops
 from ..functions import ms_deform_attn_func as _func
@@ -99,8 +99,9 @@ class MSDeformAttn(nn.Module):
         then fused into the projection GEMM); reference_points [N,Lq,L,2] (or 4: cx,cy,w,h) in [0,1];
         input_flatten [N,sum(H_l*W_l),C]; input_spatial_shapes i64 [L,2]; input_level_start_index
         i64 [L]; input_padding_mask [N,S] True = padding.  -> [N,Lq,C]   (ref :78-117)
-        post = (residual, norm): return ``norm(residual + output)`` instead - what every caller does next; on the fused
-        GPU routes the add and the LayerNorm ride in output_proj's GEMM epilogue (dfx.ops.linear(norm=...))."""
+        post = (residual, norm[, dropout]): return ``norm(residual + dropout(output))`` instead - what every caller does
+        next; on the fused GPU routes, and when the dropout is the identity (eval mode), the add and the LayerNorm ride in
+        output_proj's GEMM epilogue (dfx.ops.linear(norm=...))."""
         N, Lq, _ = (query[0] if isinstance(query, tuple) else query).shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -128,11 +129,11 @@ class MSDeformAttn(nn.Module):
                                 row_mask=input_padding_mask, col_block=4)
             qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous(), col_block=12)
             sampled = _ops.msda_level_forward(value, reference_points, qproj, N, host[0][0], host[0][1])
-            if post is not None and self.d_model == 256:
+            if post_is_fusable(post) and self.d_model == 256:
                 return _ops.linear(sampled, self.output_proj.weight, self.output_proj.bias, x_blocked=True,
                                    residual=post[0].contiguous(), norm=post[1]).view(N, Lq, -1)
             out = _ops.linear(sampled, self.output_proj.weight, self.output_proj.bias, x_blocked=True).view(N, Lq, -1)
-            return out if post is None else post[1](post[0] + out)
+            return apply_post(post, out)
         if fused:
             # value_proj (+ masked_fill of padded tokens), [offsets | logits] in one GEMM (+ the
             # caller's ``src + pos`` add when handed over as a (src, pos) pair), fused sampling
@@ -143,11 +144,11 @@ class MSDeformAttn(nn.Module):
             qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous())
             sampled = _ops.msda_fused_forward(value.view(N, S, M, D), input_spatial_shapes, input_level_start_index,
                                               reference_points, qproj, L, P)
-            if post is not None and self.d_model == 256:
+            if post_is_fusable(post) and self.d_model == 256:
                 return _ops.linear(sampled, self.output_proj.weight, self.output_proj.bias, residual=post[0].contiguous(),
                                    norm=post[1])
             out = self.output_proj(sampled)
-            return out if post is None else post[1](post[0] + out)
+            return apply_post(post, out)
         if isinstance(query, tuple):
             query = query[0] + query[1]
 
@@ -176,4 +177,4 @@ class MSDeformAttn(nn.Module):
             sampled = _func.MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                                        locations, weights, self.im2col_step)
         out = self.output_proj(sampled)
-        return out if post is None else post[1](post[0] + out)
+        return apply_post(post, out)

@@ -100,7 +100,7 @@ class RCNNHead(nn.Module):
         if fused_mha.usable(self.self_attn, pro_features):
             # batch-first all the way: residual + LayerNorm ride in out_proj's GEMM epilogue
             pf = pro_features.reshape(N, nr_boxes, self.d_model)
-            q = fused_mha.forward(self.self_attn, pf, pf, pf, post=(pf, self.norm1)).reshape(1, N * nr_boxes, self.d_model)
+            q = fused_mha.forward(self.self_attn, pf, pf, pf, post=(pf, self.norm1, self.dropout1)).reshape(1, N * nr_boxes, self.d_model)
         else:
             attn = self.self_attn(q, q, value=q)[0]
             q = _norm_add(self.norm1, q, self.dropout1(attn))
@@ -116,4 +116,4 @@ class RCNNHead(nn.Module):
             hdn = _ops.linear(obj.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
         else:
             hdn = self.activation(self.linear1(obj))
-        return _linear_norm_add(self.linear2, self.dropout(hdn), self.norm3, obj)
+        return _linear_norm_add(self.linear2, self.dropout(hdn), self.norm3, obj, dropout=self.dropout3)

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from models.fused import Linear
+from models.fused import Linear, apply_post
 
 from models.ops.modules import MSDeformAttn
 from util.memo import memo_on
@@ -52,23 +52,29 @@ def _linear_act(linear, activation, x):
 def _mha(module, q, k, v, post=None):
     """nn.MultiheadAttention on batch-first [B,L,E] tensors (no masks, attention weights unused): the fused
     GEMM + attention-kernel route in GPU inference (models/fused_mha.py), the module itself otherwise.
-    post = (residual, norm): -> norm(residual + attention output) (in out_proj's GEMM epilogue on the fused route)."""
+    post = (residual, norm, dropout): -> norm(residual + dropout(attention output)) (in out_proj's GEMM epilogue on the fused
+    route when the dropout is the identity)."""
     from . import fused_mha
     if fused_mha.usable(module, q, k, v):
         return fused_mha.forward(module, q, k, v, post)
     out = module(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1))[0].transpose(0, 1)
-    return out if post is None else post[1](post[0] + out)
+    return apply_post(post, out)
 
 
 def _gpu_inference(x):
     return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
-def _linear_norm_add(linear, x, norm, residual=None, act=None, act_first=False):
-    """norm(residual + act(linear(x))) (act_first) or norm(act(linear(x) + residual)); one MFMA GEMM launch with the
+def _identity_dropout(dropout):
+    return dropout is None or not dropout.training or dropout.p == 0
+
+
+def _linear_norm_add(linear, x, norm, residual=None, act=None, act_first=False, dropout=None):
+    """norm(residual + dropout(act(linear(x)))) (act_first) or norm(act(linear(x) + residual)); one MFMA GEMM launch with the
     residual add and the LayerNorm in its epilogue in GPU inference when the Linear ends in d_model = 256 columns
-    (dfx.ops.linear(norm=...)), the separate ops otherwise."""
-    if _gpu_inference(x) and linear.out_features == 256 and linear.in_features % 4 == 0 and linear.weight.dtype == torch.float32:
+    (dfx.ops.linear(norm=...)) and the sub-layer's Dropout is the identity (eval mode), the separate ops otherwise."""
+    if (_gpu_inference(x) and linear.out_features == 256 and linear.in_features % 4 == 0 and linear.weight.dtype == torch.float32
+            and _identity_dropout(dropout)):
         from dfx import ops as _ops
         return _ops.linear(x.contiguous(), linear.weight, linear.bias, act=act, residual=None if residual is None else residual.contiguous(),
                            norm=norm, act_first=act_first)
@@ -76,6 +82,8 @@ def _linear_norm_add(linear, x, norm, residual=None, act=None, act_first=False):
     fn = {None: None, "relu": F.relu, "gelu": F.gelu}[act]
     if fn is not None and act_first:
         y = fn(y)
+    if dropout is not None:
+        y = dropout(y)
     if residual is not None:
         y = residual + y
     if fn is not None and not act_first:
@@ -184,14 +192,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
             query = _add_pos(src, pos)
         if fused:       # residual add + LayerNorm in output_proj's epilogue
             src = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask,
-                                 post=(src, self.norm1))
+                                 post=(src, self.norm1, self.dropout1))
         else:
             y = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask)
             src = _norm_add(self.norm1, src, self.dropout1(y))
         if fused and self.activation is F.relu:
             from dfx import ops as _ops            # linear1 + bias + ReLU in one MFMA GEMM, linear2 + residual + LayerNorm in another
             h = _ops.linear(src.contiguous(), self.linear1.weight, self.linear1.bias, relu=True)
-            return _linear_norm_add(self.linear2, h, self.norm2, src)
+            return _linear_norm_add(self.linear2, self.dropout2(h), self.norm2, src, dropout=self.dropout3)
         return self.forward_ffn(src)
 
 
@@ -242,7 +250,8 @@ class _CrossFusionBlock(nn.Module):
         if (self.activation is F.gelu and tgt.is_cuda and tgt.dtype == torch.float32 and not torch.is_grad_enabled()):
             from dfx import ops as _ops            # Linear + bias + exact GELU in one MFMA GEMM
             # Linear + bias + exact GELU + residual + LayerNorm in one MFMA GEMM
-            return _linear_norm_add(self.linear1, tgt, getattr(self, self._ffn_norm), tgt, act="gelu", act_first=True)
+            return _linear_norm_add(self.linear1, tgt, getattr(self, self._ffn_norm), tgt, act="gelu", act_first=True,
+                                    dropout=getattr(self, self._ffn_drop))
         y = self.activation(self.linear1(tgt))
         return _norm_add(getattr(self, self._ffn_norm), tgt, getattr(self, self._ffn_drop)(y))
 
@@ -251,7 +260,7 @@ class _CrossFusionBlock(nn.Module):
         fused = tgt.is_cuda and not torch.is_grad_enabled() and tgt.dtype == torch.float32 and query_pos is not None
         query = (tgt, query_pos) if fused else _add_pos(tgt, query_pos)
         y = self.cross_attn(query, reference_points, src, src_spatial_shapes, src_start_index, src_padding_mask)
-        tgt = _linear_norm_add(self.cross_scale_adapt, y, self.norm1, tgt)
+        tgt = _linear_norm_add(self.cross_scale_adapt, y, self.norm1, tgt, dropout=self.dropout1)
         return self.forward_ffn(tgt)
 
 
@@ -339,14 +348,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt,
+                                dropout=self.dropout4)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2))
+        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2, self.dropout2))
         tgt = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                              level_start_index, src_padding_mask, post=(tgt, self.norm1))
+                              level_start_index, src_padding_mask, post=(tgt, self.norm1, self.dropout1))
         return self.forward_ffn(tgt)
 
 
@@ -436,19 +446,20 @@ class TemporalQueryEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt,
+                                dropout=self.dropout4)
 
     def forward(self, query, ref_query, query_pos=None, ref_query_pos=None, ref_kv=None):
         """ref_kv [B,Lk,2E]: the cross-attention's key / value projections of ``ref_query``, when the caller gathered them from
         a pool it projected once (``project_ref_pool``; GPU inference route); ``ref_query`` is then not read."""
         qk = _add_pos(query, query_pos)
-        tgt = _mha(self.self_attn, qk, qk, query, post=(query, self.norm2))
+        tgt = _mha(self.self_attn, qk, qk, query, post=(query, self.norm2, self.dropout2))
         if ref_kv is not None:
             from . import fused_mha
-            tgt = fused_mha.forward(self.cross_attn, _add_pos(tgt, query_pos), None, None, post=(tgt, self.norm1), kv=ref_kv)
+            tgt = fused_mha.forward(self.cross_attn, _add_pos(tgt, query_pos), None, None, post=(tgt, self.norm1, self.dropout1), kv=ref_kv)
         else:
             tgt = _mha(self.cross_attn, _add_pos(tgt, query_pos), _add_pos(ref_query, ref_query_pos), ref_query,
-                       post=(tgt, self.norm1))
+                       post=(tgt, self.norm1, self.dropout1))
         return self.forward_ffn(tgt)
 
     def project_ref_pool(self, pool):
@@ -496,12 +507,13 @@ class TemporalDeformableTransformerEncoderLayer(nn.Module):
     with_pos_embed = staticmethod(_add_pos)
 
     def forward_ffn(self, tgt):
-        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt)
+        return _linear_norm_add(self.linear2, self.dropout3(_linear_act(self.linear1, self.activation, tgt)), self.norm3, tgt,
+                                dropout=self.dropout4)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, frame_start_index,
                 src_padding_mask=None):
         qk = _add_pos(tgt, query_pos)
-        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2))
+        tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2, self.dropout2))
         tgt = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                              frame_start_index, src_padding_mask, post=(tgt, self.norm1))
+                              frame_start_index, src_padding_mask, post=(tgt, self.norm1, self.dropout1))
         return self.forward_ffn(tgt)

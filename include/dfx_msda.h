@@ -66,6 +66,12 @@ int dfx_profile_enable(int on);
 int dfx_profile_drain(float *ms, long *bytes, int *lq, int *s, int cap);
 
 /*
+ * The launchers' DFX_* tuning / diagnostic environment switches are read once per process;
+ * this re-reads them (A/B tools and tests that change the environment of a running process).
+ */
+int dfx_tuning_reload(void);
+
+/*
  * Forward: out[b,q,m,c] = sum_{l,p} aw[b,q,m,l,p] * bilinear(value_l[b,:,m,c], x*W_l-0.5, y*H_l-0.5)
  * Replaces ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:20-80) and the
  * kernel ms_deformable_im2col_gpu_kernel (ms_deform_im2col_cuda.cuh:237-299).

@@ -234,4 +234,61 @@ def run_cases(ns, device="cpu"):
     res = tr(srcs, masks, poss, [], [], [], qe, class_embed, [])
     put("multi_baseline", hs=res[0], final_hs=res[5], final_refs=res[6])
 
+    # ---- TransVOD transformer + Late Fusion (deformable_transformer_multi.py:193-378 with use_depth) -----------------
+    tr = tm.DeformableTransformer(d_model=256, nhead=8, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=1024,
+                                  dropout=0.1, activation="relu", return_intermediate_dec=True, num_feature_levels=1,
+                                  dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=Q,
+                                  n_temporal_decoder_layers=1, num_ref_frames=R, fixed_pretrained_model=False, args=None,
+                                  use_depth=True, depth_type="DepthDeform_latefusion_dformer", dpth_n_points=4).eval()
+    fill_params_by_name(tr, seed=35)
+    tr.decoder.bbox_embed = box_heads(2, seed=36)
+    class_embed = fill_params_by_name(torch.nn.Linear(256, 3), seed=37, prefix="class_embed.")
+    srcs, masks, poss, dsrcs, dmasks, dposs = transformer_inputs(130, R + 1, [(6, 8)], True)
+    masks = [torch.zeros_like(m) for m in masks]
+    dmasks = [torch.zeros_like(m) for m in dmasks]
+    poss = [pe(NestedTensor(s, m)) for s, m in zip(srcs, masks)]
+    dposs = [pe(NestedTensor(s, m)) for s, m in zip(dsrcs, dmasks)]
+    qe = rnd(140, Q, 512)
+    res = tr(srcs, masks, poss, dsrcs, dmasks, dposs, qe, class_embed, [])
+    put("multi_latefusion", hs=res[0], init_ref=res[1], inter_refs=res[2], final_hs=res[5], final_refs=res[6])
+
+    return blobs
+
+
+def run_train_cases(ns):
+    """The blocks' TRAIN-mode forward (sub-layer Dropouts active, p = 0.2 as every shipped config sets it) under a fixed
+    global seed, CPU only: the reference applies ``norm(residual + dropout(sublayer(x)))``
+    (deformable_transformer_single.py:375,396,545-557,625-643; deformable_transformer_multi_plusplus.py:815-838;
+    sparse_roi_head/head.py:75-80).  Both sides draw their masks from the same generator state, so an implementation that
+    skips a Dropout, applies it to another tensor layout or in another order differs at once."""
+    ts, tpp, RCNNHead = ns.ts, ns.tpp, ns.RCNNHead
+    global _DEVICE
+    _DEVICE = "cpu"
+    blobs = {}
+    p = 0.2
+
+    def run(case, layer, seed, *args):
+        layer = _fill_by_name(layer, seed=seed).train()
+        torch.manual_seed(2024)
+        blobs[f"{case}.out"] = layer(*args).detach().cpu()
+
+    shapes, lsi, S = levels([(6, 8)])
+    grid = ts.DeformableTransformer.get_reference_points(shapes, torch.ones(2, 1, 2), "cpu")
+    src, pos, depth = rnd(10, 2, S, 256), rnd(11, 2, S, 256), rnd(15, 2, S, 256)
+    tgt, qpos = rnd(12, 2, 21, 256), rnd(13, 2, 21, 256)
+    ref4 = urnd(14, 2, 21, 1, 4) * torch.tensor([1, 1, 0.4, 0.4])
+    run("train_enc_layer", ts.DeformableTransformerEncoderLayer(256, 1024, p, "relu", 1, 8, 4), 2, src, pos, grid, shapes, lsi, None)
+    run("train_dec_layer", ts.DeformableTransformerDecoderLayer(256, 1024, p, "relu", 1, 8, 4), 3,
+        tgt, qpos, ref4, src, shapes, lsi, None)
+    run("train_latefusion_layer", ts.DepthDeformableTransformerEncoderLayer(256, 1024, p, "relu", 1, 8, 4, True, True, True), 4,
+        src, pos, None, shapes, grid, None, depth, shapes, lsi, None, None)
+    run("train_fusion_v2_layer", ts.DeformableTransformerFusionLayerV2(256, 1024, p, "relu", 1, 8, 4), 5,
+        src, pos, grid, depth, shapes, lsi, None)
+    run("train_tqe_layer", tpp.TemporalQueryEncoderLayer(256, 1024, p, "relu", 8), 6, tgt[:1], rnd(16, 1, 55, 256))
+    run("train_tdtd_layer", tpp.TemporalDeformableTransformerEncoderLayer(256, 1024, p, "relu", 1, 8, 4), 7,
+        tgt, qpos, ref4[:, :, :, :2].contiguous(), src, shapes, lsi, None)
+    cfg = {"MODEL": {"SparseRCNN": {"NHEADS": 8, "DROPOUT": 0.0, "DIM_FEEDFORWARD": 2048, "ACTIVATION": "relu",
+                                    "HIDDEN_DIM": 256, "NUM_CLS": 1, "NUM_REG": 3, "NUM_HEADS": 6, "NUM_DYNAMIC": 2,
+                                    "DIM_DYNAMIC": 64}, "ROI_BOX_HEAD": {"POOLER_RESOLUTION": 7}}}
+    run("train_rcnn_head", RCNNHead(cfg, 256, 3, 1024, 8, p, "relu"), 8, rnd(17, 42, 256, 7, 7), rnd(18, 2, 21, 256))
     return blobs

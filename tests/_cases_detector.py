@@ -223,6 +223,33 @@ def run_detector_cases(ns, device="cpu"):
     for i, (vals, idx) in enumerate(round_picks(rec.calls, R)):
         put("det_multipp_rgb", **{f"topk{i}_values": vals, f"topk{i}_idx": idx})
     post("det_multipp_rgb", ns.multipp, out, torch.as_tensor([[360, 480]], device=device), keep_prob=0.5)
+
+    # ---- TransVOD (``--dataset_file vid_multi``, models/deformable_detr_multi.py:45-311 around
+    # deformable_transformer_multi.py:193-378): one pair of temporal heads, the transformer gets only class_embed[-1],
+    # the three picks rank ``sigmoid(logits)[:, :, :-1]`` - Late Fusion and RGB ---------------------------------------
+    if hasattr(ns, "multi"):
+        for case, use_depth, seed, R, Q, keep in (("det_multi", True, 81, 2, 90, 0.02), ("det_multi_rgb", False, 91, 3, 60, 0.3)):
+            dt = dtype_str if use_depth else "Baseline_rgb"
+            tr = ns.tm.DeformableTransformer(d_model=256, nhead=8, num_encoder_layers=2, num_decoder_layers=2,
+                                             dim_feedforward=1024, dropout=0.1, activation="relu", return_intermediate_dec=True,
+                                             num_feature_levels=1, dec_n_points=4, enc_n_points=4, two_stage=False,
+                                             two_stage_num_proposals=Q, n_temporal_decoder_layers=1, num_ref_frames=R,
+                                             fixed_pretrained_model=False, args=None, use_depth=use_depth, depth_type=dt,
+                                             dpth_n_points=4)
+            det = ns.multi.DeformableDETR(StubJoiner(pe, NTM, 2048, seed + 1),
+                                          StubJoiner(pe, NTM, 128, seed + 2, depth=True) if use_depth else None, tr,
+                                          num_classes=3, num_queries=Q, num_feature_levels=1, num_ref_frames=R, aux_loss=True,
+                                          with_box_refine=True, two_stage=False, use_depth=use_depth, depth_type=dt).eval()
+            fill_params_by_name(det, seed=seed)
+            put_state_dict(case, det)
+            det = det.to(device)
+            x = _rnd(seed + 3, R + 1, 4 if use_depth else 3, H, W).to(device)
+            with TopkRecorder() as rec:
+                out = det(NTM(x, torch.zeros(R + 1, H, W, dtype=torch.bool, device=device)))
+            put(case, pred_logits=out["pred_logits"], pred_boxes=out["pred_boxes"])
+            for i, (vals, idx) in enumerate(round_picks(rec.calls, R)):
+                put(case, **{f"topk{i}_values": vals, f"topk{i}_idx": idx})
+            post(case, ns.multi, out, torch.as_tensor([[480, 640]], device=device), keep_prob=keep)
     return blobs
 
 

@@ -33,3 +33,22 @@ def cpu_msda(oracle, monkeypatch):
     import models.ops.functions.ms_deform_attn_func as f
     monkeypatch.setattr(f, "MSDeformAttnFunction", oracle.OracleMSDAFunction)
     return oracle
+
+
+@pytest.fixture()
+def dfx_env(monkeypatch):
+    """Change a DFX_* tuning switch of libdfx.so in the running process: ``dfx_env(name, value)`` (value None = unset).
+    The library reads its switches once (csrc/dfx_common.h:Tuning), so every change is followed by a reload; the
+    environment and the library's view of it are restored at teardown."""
+    from dfx import ops
+
+    def change(name, value):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        ops.reload_tuning()
+
+    yield change
+    monkeypatch.undo()
+    ops.reload_tuning()

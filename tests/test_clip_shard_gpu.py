@@ -41,7 +41,7 @@ def _worker(rank, world, port, result_path):
     try:
         from models.clip_inference import ClipRunner
         torch.cuda.set_device(0)
-        torch.backends.cudnn.deterministic = True     # MIOpen's default solvers are not run-to-run deterministic
+        torch.backends.cudnn.deterministic = True     # library solvers are not run-to-run deterministic
         model = _build()
         clip = _clip()
         per = clip.shape[0] // world
@@ -82,7 +82,7 @@ def test_two_stream_schedule_gives_identical_outputs():
     from models.clip_inference import ClipRunner
     model = _build()
     clip = torch.randn(6, 4, 64, 96, generator=torch.Generator().manual_seed(12)).cuda()
-    # MIOpen's default solvers for some small convolutions are not run-to-run deterministic on this stack
+    # library solvers for some small convolutions are not run-to-run deterministic on this stack
     # (tools/determinism_check.py); ask for deterministic ones so that "same bits" can be asserted
     saved = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True
@@ -210,8 +210,7 @@ model = _build()
 clip = _clip().cuda()
 want = ClipRunner(model, micro_batch=4)(clip)                       # no process group: no exchange
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL
-runner = ClipRunner(model, micro_batch=4)
-runner.gather_on_one_rank = True                                     # run the collective although world == 1
+runner = ClipRunner(model, micro_batch=4, gather_on_one_rank=True)   # run the collective although world == 1
 got = runner(clip)                                                   # all_gather_into_tensor on the current stream
 outs = [runner.submit(clip) for _ in range(3)]                       # ... and on the side stream of the clip pipeline
 torch.cuda.synchronize()

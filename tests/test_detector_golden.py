@@ -21,15 +21,17 @@ TIE_MARGIN = 2e-5
 
 
 def my_namespace():
+    import models.deformable_detr_multi as multi
     import models.deformable_detr_multi_plusplus as multipp
     import models.backbone_scratch as bsc
     import models.deformable_detr_single as single
+    import models.deformable_transformer_multi as tm
     import models.deformable_transformer_multi_plusplus as tpp
     import models.deformable_transformer_single as ts
     from models.position_encoding import PositionEmbeddingSine
     from util.misc import NestedTensor
     from util.misc_multi import NestedTensor as NestedTensorMulti
-    return SimpleNamespace(bsc=bsc, single=single, multipp=multipp, ts=ts, tpp=tpp, NestedTensor=NestedTensor,
+    return SimpleNamespace(bsc=bsc, single=single, multipp=multipp, multi=multi, ts=ts, tpp=tpp, tm=tm, NestedTensor=NestedTensor,
                            NestedTensorMulti=NestedTensorMulti, PositionEmbeddingSine=PositionEmbeddingSine)
 
 
@@ -68,7 +70,7 @@ def check(got, golden):
             assert err < 2e-4 * scale, f"{key}: max abs err {err:.3e}"
             report[key] = err
     # int64: ordered index tensors, compared outside the tie margin
-    for case in ("det_single", "det_multipp", "det_multipp_rgb"):
+    for case in ("det_single", "det_multipp", "det_multipp_rgb", "det_multi", "det_multi_rgb"):
         scores = torch.from_numpy(golden[f"{case}.pp_scores"])
         for name in ("pp_labels", "pp_box_idx"):
             n, bad = compare_indices(torch.from_numpy(golden[f"{case}.{name}"]), got[f"{case}.{name}"], scores, TIE_MARGIN)
@@ -79,7 +81,7 @@ def check(got, golden):
         clear = (p - float(golden[f"{case}.keep_prob"])).abs() > TIE_MARGIN
         assert torch.equal(got[f"{case}.keep_mask"][clear], torch.from_numpy(golden[f"{case}.keep_mask"])[clear])
         assert 0 < int(golden[f"{case}.keep_mask"].sum()) < p.numel(), "the fixture's keep mask must be non-trivial"
-    for case, i in ((c, i) for c in ("det_multipp", "det_multipp_rgb") for i in range(3)):
+    for case, i in ((c, i) for c in ("det_multipp", "det_multipp_rgb", "det_multi", "det_multi_rgb") for i in range(3)):
         ref_idx, vals = torch.from_numpy(golden[f"{case}.topk{i}_idx"]), torch.from_numpy(golden[f"{case}.topk{i}_values"])
         n, bad = compare_indices(ref_idx, got[f"{case}.topk{i}_idx"], vals, TIE_MARGIN)
         assert n >= 0.8 * ref_idx.numel() and bad == 0, f"{case} temporal top-k {i}: {bad} of {n} clear ranks differ"

@@ -43,7 +43,7 @@ def test_linear_matches_fp64(M, N, K, variant):
 @pytest.mark.parametrize("M,N,K", [(1200, 256, 256), (300, 96, 256), (2400, 512, 512), (37, 256, 1024), (4800, 32, 256),
                                    (1201, 480, 1024), (1200, 4, 256), (700, 3, 1024), (64, 2, 512), (1200, 1024, 256)])
 @pytest.mark.parametrize("variant", ["plain", "bias_relu", "add_res_gelu"])
-def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, monkeypatch):
+def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, dfx_env):
     """Few rows (the 300-query layers): one 32 x 32 tile per workgroup, K split over its waves (csrc/gemm_f32.hip,
     linear_rows_kernel) - against fp64 and against the tile kernel on the same operands (DFX_GEMM_NO_ROWS=1)."""
     from dfx import ops
@@ -58,9 +58,9 @@ def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, m
     got = ops.linear(x, w, b, residual=res, add=add, act=act)
     tiles = [tb for (_, _, ta, tb) in ops.profile_stop() if ta == -2]
     assert tiles == [32032], "the rows kernel serves this shape"
-    monkeypatch.setenv("DFX_GEMM_NO_ROWS", "1")
+    dfx_env("DFX_GEMM_NO_ROWS", "1")
     other = ops.linear(x, w, b, residual=res, add=add, act=act)
-    monkeypatch.delenv("DFX_GEMM_NO_ROWS")
+    dfx_env("DFX_GEMM_NO_ROWS", None)
     y = (x.double() + (add.double() if add is not None else 0)) @ w.double().t()
     if b is not None:
         y = y + b.double()
@@ -76,12 +76,12 @@ def test_linear_rows_kernel_matches_fp64_and_the_tile_kernel(M, N, K, variant, m
 
 @pytest.mark.parametrize("M,N,K,w", [(4200, 256, 256, 4), (8400, 96, 256, 12), (333, 96, 64, 12), (130, 256, 260, 8),
                                      (5, 12, 8, 4)])
-def test_linear_block_major_layouts(M, N, K, w, monkeypatch):
+def test_linear_block_major_layouts(M, N, K, w, dfx_env):
     """col_block stores C as [N/w][M][w]; x_blocked reads A as [K/4][M][4] - the layouts between the
     projections and the level-in-LDS MSDA kernel.  Same arithmetic as the row-major call of the tile kernel: equal bits
     (the few-row kernel, which serves row-major operands only, sums K in another order: kept out of the comparison)."""
     from dfx import ops
-    monkeypatch.setenv("DFX_GEMM_NO_ROWS", "1")
+    dfx_env("DFX_GEMM_NO_ROWS", "1")
     g = torch.Generator().manual_seed(M * 7 + N + K + w)
     x = torch.randn(M, K, generator=g).cuda()
     wt = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
@@ -164,12 +164,12 @@ def test_box_refine_matches_torch(rows, ref_dim):
                                           (1, 65, 33, "cross"), (2, 1, 1, "same"), (2, 64, 32, "self_pos"),
                                           (1, 31, 95, "cross"), (40, 300, 300, "same")])
 @pytest.mark.parametrize("groups", [None, "1", "2", "4"])
-def test_fused_mha_matches_module(B, Lq, Lk, mode, groups, monkeypatch):
+def test_fused_mha_matches_module(B, Lq, Lk, mode, groups, dfx_env):
     """models/fused_mha.py (GEMM projections + csrc/mha.hip) against nn.MultiheadAttention in eval mode; the key range split
     over 1 / 2 / 4 wave groups of a workgroup (None: the launch's own choice)."""
     from models import fused_mha
     if groups is not None:
-        monkeypatch.setenv("DFX_MHA_GROUPS", groups)
+        dfx_env("DFX_MHA_GROUPS", groups)
     torch.manual_seed(B * 1000 + Lq + Lk)
     mod = torch.nn.MultiheadAttention(256, 8, dropout=0.1).cuda().eval()
     with torch.no_grad():
@@ -267,7 +267,7 @@ def test_group_norm_matches_torch(N, C, H, W):
     assert b.flatten(2).transpose(1, 2).is_contiguous()       # what the transformer does next is free
 
 
-def test_lds_dma_staging_is_bit_identical_to_register_staging_repeatedly(monkeypatch):
+def test_lds_dma_staging_is_bit_identical_to_register_staging_repeatedly(dfx_env):
     """The LDS-DMA staged kernel (default) against the register-staged one (DFX_GEMM_NO_DMA=1) on the same operands,
     many launches per shape: identical bits every time - a landing-order race would show up as a stray tile."""
     from dfx import ops
@@ -286,9 +286,9 @@ def test_lds_dma_staging_is_bit_identical_to_register_staging_repeatedly(monkeyp
             w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).cuda()
             b = torch.randn(Co, generator=g).cuda()
             run = lambda: ops.conv1x1(x, w, b, relu=True)
-        monkeypatch.setenv("DFX_GEMM_NO_DMA", "1")
+        dfx_env("DFX_GEMM_NO_DMA", "1")
         ref = run()
-        monkeypatch.delenv("DFX_GEMM_NO_DMA")
+        dfx_env("DFX_GEMM_NO_DMA", None)
         for _ in range(25):
             assert torch.equal(run(), ref), (kind, shape)
 

@@ -94,3 +94,28 @@ def test_encoder_cf_uses_norm2_in_fusion_layers():
     keys = set(t.state_dict())
     assert "encoder.fusion_layers.3.norm2.weight" in keys and "encoder.fusion_layers.0.norm3.weight" not in keys
     assert "encoder.fusion_layers.0.depth_scale_adapt.weight" in keys
+
+
+def test_train_mode_blocks_match_the_reference_under_a_fixed_seed(golden_dir, cpu_msda):
+    """The sub-layer Dropouts (p = 0.2 in every shipped config) are applied where the reference applies them - to the same
+    tensor, in the same order - so that a train-mode forward draws the same masks from the same generator state
+    (tests/_cases.py:run_train_cases; fixture from the reference's modules, tools/gen_golden_models.py)."""
+    from tests._cases import run_train_cases
+    ref = np.load(os.path.join(golden_dir, "train_mode.npz"))
+    with torch.no_grad():
+        got = run_train_cases(my_namespace())
+    assert set(got) == set(ref.files) and len(got) == 7
+    for key in sorted(got):
+        err = (got[key] - torch.from_numpy(ref[key])).abs().max().item()
+        assert err < 2e-4, f"{key}: max abs err {err:.3e}"
+
+
+def test_train_mode_differs_from_eval():
+    """... and a dropped Dropout would show: with an active Dropout the fused-epilogue helper must not return the eval result."""
+    from models.transformer_layers import _linear_norm_add
+    x = torch.randn(2, 5, 256)
+    lin, norm, drop = torch.nn.Linear(256, 256), torch.nn.LayerNorm(256), torch.nn.Dropout(0.5)
+    torch.manual_seed(0)
+    a = _linear_norm_add(lin, x, norm, x, dropout=drop.train())
+    b = _linear_norm_add(lin, x, norm, x, dropout=drop.eval())
+    assert not torch.allclose(a, b) and torch.allclose(b, norm(x + lin(x)), atol=1e-6)

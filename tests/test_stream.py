@@ -76,7 +76,7 @@ def test_video_stream_matches_the_reference_caller(golden, name, blocks, cpu_msd
     assert not stream.pending and len(stream.bank) <= v["R"] + max(blocks) + 1
 
 
-def _worker(rank, world, port, name, out_path):
+def _worker(rank, world, port, name, out_path, n_frames=8):
     for p in (PKG, ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -88,13 +88,29 @@ def _worker(rank, world, port, name, out_path):
     try:
         from models.clip_inference import ClipRunner, VideoStream
         v = VIDEOS[name]
-        frames = video_frames(name)[:8]                       # 8 frames: blocks of 2 x 2 frames
+        frames = video_frames(name)[:n_frames]                # blocks of 2 x 2 frames
         det = build_detector(my_namespace(), v["R"], v["depth"])
         stream = VideoStream(ClipRunner(det, micro_batch=2))
         mine = []
-        for b in range(0, 8, 4):
-            block = frames[b + 2 * rank:b + 2 * rank + 2]
-            mine += stream.push(block, last=(b == 4))
+        if n_frames == 7 and rank == 1:                       # a rank passing another block size is told so, not hung
+            try:
+                stream.push(frames[:1])
+                raise AssertionError("unequal blocks must be refused")
+            except ValueError as e:
+                assert "same number of frames" in str(e)
+        elif n_frames == 7:
+            try:
+                stream.push(frames[:2])
+                raise AssertionError("unequal blocks must be refused")
+            except ValueError:
+                pass
+        for b in range(0, n_frames, 4):
+            left = n_frames - b
+            if left >= 4:
+                mine += stream.push(frames[b + 2 * rank:b + 2 * rank + 2], last=(left == 4))
+            else:       # the tail: 3 frames left for 2 x 2 slots - the last frame repeated, pad = 1
+                idx = [min(b + 2 * rank + i, n_frames - 1) for i in range(2)]
+                mine += stream.push_tail(frames[idx], pad=4 - left)
         gathered = [None] * world
         dist.all_gather_object(gathered, [(t, {k: o[k] for k in o}) for t, o in mine])
         if rank == 0:
@@ -119,6 +135,27 @@ def test_video_stream_on_two_ranks_matches_one_rank(tmp_path, cpu_msda):
     single = dict(stream.push(video_frames("long_rgbd")[:8], last=True))
     assert sorted(sharded) == sorted(single) == list(range(8))
     for t in range(8):
+        for k in ("pred_logits", "pred_boxes"):
+            assert torch.allclose(sharded[t][k], single[t][k], atol=1e-5), (t, k)
+
+
+@pytest.mark.timeout(600)
+def test_video_stream_uneven_tail_on_two_ranks(tmp_path, cpu_msda):
+    """A 7-frame video on 2 ranks x 2 frames per push: the last push carries 3 real frames + 1 repeated one (``push_tail``,
+    pad = 1); outputs equal the single-process stream's, no output for the repeat; a push whose block size differs between
+    the ranks raises on every rank instead of hanging in the all-gather."""
+    from models.clip_inference import ClipRunner, VideoStream
+    from tests.test_clip_shard_gloo import _patch_cpu_ops
+    port = 31900 + os.getpid() % 2000
+    path = str(tmp_path / "stream7.pt")
+    mp.spawn(_worker, args=(2, port, "long_rgbd", path, 7), nprocs=2, join=True)
+    sharded = {t: o for part in torch.load(path) for t, o in part}
+    _patch_cpu_ops()
+    v = VIDEOS["long_rgbd"]
+    stream = VideoStream(ClipRunner(build_detector(my_namespace(), v["R"], v["depth"]), micro_batch=2))
+    single = dict(stream.push(video_frames("long_rgbd")[:7], last=True))
+    assert sorted(sharded) == sorted(single) == list(range(7))
+    for t in range(7):
         for k in ("pred_logits", "pred_boxes"):
             assert torch.allclose(sharded[t][k], single[t][k], atol=1e-5), (t, k)
 

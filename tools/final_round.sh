@@ -1,6 +1,7 @@
-# end-of-round verification + the evidence that changed after profile_round.sh
+# end-of-round verification + the evidence that changed after profile_round.sh:  ROUND=r04 bash tools/final_round.sh
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03final; mkdir -p $O
+ROUND=${ROUND:-r04}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}final; mkdir -p $O
 cd $R
 python -m pytest tests -x -q -m gpu > $O/t_full.log 2>&1; tail -2 $O/t_full.log
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log

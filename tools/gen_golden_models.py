@@ -40,7 +40,7 @@ from models.position_encoding import PositionEmbeddingSine  # noqa: E402
 from models.sparse_roi_head.head import RCNNHead  # noqa: E402
 from util.misc import NestedTensor, inverse_sigmoid  # noqa: E402
 
-from tests._cases import run_cases  # noqa: E402
+from tests._cases import run_cases, run_train_cases  # noqa: E402
 
 ns = SimpleNamespace(MSDeformAttn=MSDeformAttn, ts=ts, tpp=tpp, tm=tm, RCNNHead=RCNNHead, dfb=dfb, dcf=dcf,
                      PositionEmbeddingSine=PositionEmbeddingSine, NestedTensor=NestedTensor,
@@ -48,5 +48,11 @@ ns = SimpleNamespace(MSDeformAttn=MSDeformAttn, ts=ts, tpp=tpp, tm=tm, RCNNHead=
 torch.set_grad_enabled(False)
 blobs = {k: v.numpy() for k, v in run_cases(ns).items()}
 OUT = os.path.join(ROOT, "tests", "golden", "models.npz")
+np.savez_compressed(OUT, **blobs)
+print("wrote", OUT, f"{os.path.getsize(OUT)/1e6:.2f} MB", len(blobs), "arrays")
+
+# the blocks in TRAIN mode under a fixed seed (sub-layer Dropouts active): tests/golden/train_mode.npz
+blobs = {k: v.numpy() for k, v in run_train_cases(ns).items()}
+OUT = os.path.join(ROOT, "tests", "golden", "train_mode.npz")
 np.savez_compressed(OUT, **blobs)
 print("wrote", OUT, f"{os.path.getsize(OUT)/1e6:.2f} MB", len(blobs), "arrays")

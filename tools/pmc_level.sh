@@ -1,6 +1,7 @@
-# PMC passes over the MSDA level kernel (round 3): bash tools/r03_pmc_level.sh -> gpurun_out/r03/pmc_level.txt
+# PMC passes over the MSDA level kernel: ROUND=r04 bash tools/pmc_level.sh -> gpurun_out/$ROUND/pmc_level.txt
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+ROUND=${ROUND:-r04}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for F in 8 32; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pl_fetch$F -o run -- python3 $R/tools/pmc_probe.py --frames $F > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round evidence in one GPU call: ROUND=r03 bash tools/profile_round.sh   (writes under gpurun_out/$ROUND/)
+# Round evidence in one GPU call: ROUND=r04 bash tools/profile_round.sh   (writes under gpurun_out/$ROUND/)
 set -o pipefail
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench done"
