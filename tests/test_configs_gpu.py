@@ -8,6 +8,12 @@ oracle as the two operators - at the sizes the baseline names, through ``build_m
   config C  Encoder Cross Fusion RGB-D, one 800x1333 image
   config D  TransVOD++ RGB (``--fusion_type Baseline``), 8-frame 3-channel clip: every ordered temporal pick
             (k*R = 560 / 350 / 210) and the PostProcess indices, on a small clip and at 800x1333
+  config E  TransVOD++ Late Fusion, the bench's own 32-frame 800x1333 RGB-D clip (seed 42, per-query sampling offsets,
+            R = 31): ordered picks of 2480 / 1550 / 930 and the PostProcess indices (round 4; the check bench.py prints,
+            tests/_config_e_check.py)
+  padded    ragged 2-image batches (800x1333 + 736x1200) through configs B and C, and a padded TransVOD++ clip at
+            800x1333: masks, valid ratios < 1, the scaled reference grid through the level-in-LDS MSDA kernel, the
+            row-masked block-major value projection (round 4)
 
 Weights are filled by state_dict name (tests/_param_fill.py), which spreads the class scores: the index comparisons
 cover at least 80 % of the ranks outside the 2e-5 tie margin and report how many they compared.
@@ -164,3 +170,104 @@ def test_config_a_sample_image_through_the_whole_caller(golden_dir):
             assert ta[0] == tb[0] == "Hand" and len(ta) == 6
             assert max(abs(float(u) - float(v)) for u, v in zip(ta[1:], tb[1:])) < 1e-4
     print(f"config A: {int(kept_c.sum())} detections kept, {int(clear.sum())} of 300 queries outside the tie margin of the threshold")
+
+
+@pytest.mark.timeout(1500)
+def test_config_e_32_frame_clip_800x1333():
+    """BASELINE.json configs[4] at full size as a test (it lived only inside bench.py until round 3): clip 0 of the bench
+    workload through the CPU-oracle path (one pass, ~35 s on the box's 16 cores) and through the HIP path; logits / boxes
+    within 1e-3 (measured ~1e-5), PostProcess labels / box indices and the ordered temporal picks of 80 R / 50 R / 30 R =
+    2480 / 1550 / 930 reference queries index by index on >= 80 % of the ranks, no mismatch."""
+    import bench
+    from tests import _config_e_check as chk
+    T, H, W = 32, 800, 1333
+    clip = torch.randn(T, 4, H, W, generator=torch.Generator().manual_seed(42))
+    want, heads, seconds = chk.cpu_reference_clip(bench.build, clip, min(16, os.cpu_count() or 1), timed_passes=1, warm_frames=0)
+    got = chk.hip_path_clip(bench.build, clip, heads)
+    rep = chk.compare(got, want, heads, H, W)
+    print(f"config E: CPU pass {seconds[0]:.1f} s;", rep)
+    assert rep["max_abs_diff_pred_logits"] < 1e-3 and rep["max_abs_diff_pred_boxes"] < 1e-3
+    assert [p.shape for p in want["topk"]] == [(T, 80 * 31), (T, 50 * 31), (T, 30 * 31)]
+    for r in [rep["postprocess_box_idx"], rep["postprocess_labels"]] + rep["temporal_topk_ordered"]:
+        assert r["share"] >= 0.8 and r["mismatches"] == 0, r
+    assert rep["postprocess_box_idx"]["of"] == T * 100 and rep["temporal_topk_ordered"][0]["of"] == T * 2480
+
+
+def _ragged_pair():
+    g = torch.Generator().manual_seed(77)
+    return [torch.randn(4, 800, 1333, generator=g), torch.randn(4, 736, 1200, generator=g)]
+
+
+@pytest.mark.parametrize("fusion", ["LateFusion", "Encoder_CrossFusion"])
+@pytest.mark.timeout(1200)
+def test_padded_batch_at_production_size(fusion, monkeypatch):
+    """util/misc.py:338-356 pads a ragged batch; deformable_transformer_single.py:155-177 turns the mask into valid ratios
+    < 1 and a scaled reference grid.  Two images, 800x1333 and 736x1200 (46 x 75 valid tokens of the 50 x 84 map), through
+    configs B and C: the level-in-LDS MSDA kernel (4200 queries per image >= LEVEL_MIN_QUERIES), the row-masked block-major
+    value projection and the scaled grid see a real mask.  The decoder reads the memory through masked attention only, so
+    logits and boxes of both images are comparable in full; PostProcess indices outside the tie margin."""
+    from dfx import ops
+    from models.config import single_args
+    from models.fused import enable_fused_inference
+    from util.misc import nested_tensor_from_tensor_list
+    imgs = _ragged_pair()
+    gm, post = _make(lambda d: single_args(fusion, device=d), "cuda")
+    enable_fused_inference(gm)
+    batch = nested_tensor_from_tensor_list([i.cuda() for i in imgs])
+    assert batch.tensors.shape == (2, 4, 800, 1333) and bool(batch.mask[1, 736:].all()) and bool(batch.mask[1, :, 1200:].all())
+    assert not bool(batch.mask[0].any())
+    level_calls, real_level = [], ops.msda_level_forward
+
+    def counted(value_blk, reference_points, qproj_blk, N, H, W):
+        level_calls.append((N, H, W))
+        return real_level(value_blk, reference_points, qproj_blk, N, H, W)
+
+    monkeypatch.setattr(ops, "msda_level_forward", counted)
+    with torch.no_grad():
+        got = gm(batch)
+    monkeypatch.undo()
+    # the encoder's 6 layers + the fusion layer(s) ran on the level-in-LDS kernel, on the padded batch
+    assert len(level_calls) >= 7 and all(c[0] == 2 for c in level_calls) and (2, 50, 84) in level_calls
+    f, ops_, saved = _cpu_ops()
+    try:
+        cm, _ = _make(lambda d: single_args(fusion, device=d), "cpu")
+        with torch.no_grad():
+            want = cm(nested_tensor_from_tensor_list(imgs))
+    finally:
+        f.MSDeformAttnFunction, ops_.roi_align = saved
+    frac = _check_postprocess(post, got, want, torch.tensor([[800, 1333], [736, 1200]]))
+    # the padding matters: the padded image alone, unpadded, gives other logits than inside the batch's mask geometry
+    print(f"{fusion}, ragged batch at production size: {frac:.0%} of the PostProcess ranks compared index by index")
+
+
+@pytest.mark.timeout(1500)
+def test_padded_transvodpp_clip_at_production_size():
+    """A 4-frame TransVOD++ Late-Fusion clip at 800x1333 whose frames are valid on 736x1200 only (mask != 0, valid ratios
+    0.92 / 0.9): the spatial stage on the HIP path vs the CPU oracle path, compared where no PADDED token is read - class
+    logits, refined reference boxes, and the encoder memory at valid tokens (the reasoning of
+    tests/test_models_gpu.py::test_padded_clip_gpu_vs_cpu_oracle, at the size where the level kernel, the masked GEMM
+    epilogue and the block-major operands are the routes taken)."""
+    from models.clip_inference import ClipRunner
+    from models.config import transvodpp_args
+    T, H, W, vh, vw = 4, 800, 1333, 736, 1200
+    clip = torch.randn(T, 4, H, W, generator=torch.Generator().manual_seed(78))
+    mask = torch.zeros(T, H, W, dtype=torch.bool)
+    mask[:, vh:, :] = True
+    mask[:, :, vw:] = True
+    clip = clip * (~mask)[:, None]
+    args_fn = lambda d: transvodpp_args("LateFusion", num_ref_frames=T - 1, device=d)      # noqa: E731
+    gm, _ = _make(args_fn, "cuda", seed=5, temporal=True)
+    got = ClipRunner(gm, micro_batch=T).frames_forward(clip.cuda(), mask.cuda())
+    f, ops_, saved = _cpu_ops()
+    try:
+        cm, _ = _make(args_fn, "cpu", seed=5, temporal=True)
+        want = ClipRunner(cm, micro_batch=2).frames_forward(clip, mask)
+    finally:
+        f.MSDeformAttnFunction, ops_.roi_align = saved
+    assert (got["valid_ratios"].cpu() - want["valid_ratios"]).abs().max() < 1e-6 and float(want["valid_ratios"].max()) < 0.95
+    assert (got["logits"].cpu() - want["logits"]).abs().max() < 1e-3
+    assert (got["ref_last"].cpu() - want["ref_last"]).abs().max() < 1e-3
+    valid = ~torch.nn.functional.interpolate(mask[None].float(), size=(50, 84)).bool()[0].flatten(1)      # stride-16 map
+    assert int(valid[0].sum()) == 46 * 75
+    diff = (got["memory"].cpu() - want["memory"]).abs().max(-1)[0]
+    assert (diff * valid).max() < 1e-3
