@@ -62,7 +62,7 @@ def _check_inputs(named):
     for name, t in named:
         # the reference raises "Not implemented on the CPU" (ms_deform_attn.h:38,60)
         if not t.is_cuda:
-            raise RuntimeError(f"{name} must be a CUDA tensor (MSDA is not implemented on the CPU)")
+            raise RuntimeError(f"Not implemented on the CPU ({name} must be a CUDA tensor)")
     dev = named[0][1].device
     for name, t in named:
         if t.device != dev:

@@ -312,6 +312,27 @@ def walk_config(cfg, verbose=False):
     return walk.rows
 
 
+def config_entry(cfg, verbose=False):
+    """The JSON entry of one configuration (what tools/algorithmic_work.json holds under its key; tests/test_algorithmic_work.py
+    re-derives config E's and compares) -> (entry, rows, totals, parts, families)."""
+    rows = walk_config(cfg, verbose)
+    tot, parts, fams = summarise(rows, 1)
+    entry = {"per_frame": {"activation_bytes": tot["act"], "weight_bytes": tot["weights"], "bytes": tot["act"] + tot["weights"],
+                           "flops": tot["flops"]},
+             "parts": {k: v for k, v in parts.items()}, "families": {k: v for k, v in fams.items()},
+             "kernel_families": kernel_families(rows, 1)}
+    if cfg in ("D", "E"):
+        tot2, parts2, fams2 = summarise(rows, 2)
+        entry["per_frame_all_current"] = {"activation_bytes": tot2["act"], "weight_bytes": tot2["weights"],
+                                          "bytes": tot2["act"] + tot2["weights"], "flops": tot2["flops"]}
+        entry["families_all_current"] = {k: v for k, v in fams2.items()}
+        entry["kernel_families_all_current"] = kernel_families(rows, 2)
+    if PUBLISHED.get(cfg):
+        pa, pw, pf = PUBLISHED[cfg]
+        entry["baseline_md"] = {"activation_MB": pa, "weight_MB": pw, "GFLOP": pf}
+    return entry, rows, tot, parts, fams
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="A,baseline,B,C,D,E",
@@ -322,23 +343,11 @@ def main():
     doc = {}
     wanted = a.configs.split(",")
     for cfg in wanted:
-        rows = walk_config(cfg, a.verbose)
-        tot, parts, fams = summarise(rows, 1)
-        entry = {"per_frame": {"activation_bytes": tot["act"], "weight_bytes": tot["weights"], "bytes": tot["act"] + tot["weights"],
-                               "flops": tot["flops"]},
-                 "parts": {k: v for k, v in parts.items()}, "families": {k: v for k, v in fams.items()},
-                 "kernel_families": kernel_families(rows, 1)}
-        if cfg in ("D", "E"):
-            tot2, parts2, fams2 = summarise(rows, 2)
-            entry["per_frame_all_current"] = {"activation_bytes": tot2["act"], "weight_bytes": tot2["weights"],
-                                              "bytes": tot2["act"] + tot2["weights"], "flops": tot2["flops"]}
-            entry["families_all_current"] = {k: v for k, v in fams2.items()}
-            entry["kernel_families_all_current"] = kernel_families(rows, 2)
+        entry, rows, tot, parts, fams = config_entry(cfg, a.verbose)
         doc[cfg] = entry
         line = f"config {cfg}: activations {tot['act'] / 1e6:8.1f} MB  weights {tot['weights'] / 1e6:6.1f} MB  {tot['flops'] / 1e9:7.1f} GFLOP per frame"
         if PUBLISHED.get(cfg):
             pa, pw, pf = PUBLISHED[cfg]
-            entry["baseline_md"] = {"activation_MB": pa, "weight_MB": pw, "GFLOP": pf}
             line += (f"   (BASELINE.md: {pa} MB + {pw} MB, {pf} GFLOP: {tot['act'] / 1e6 / pa - 1:+.1%} / "
                      f"{tot['weights'] / 1e6 / pw - 1:+.1%} / {tot['flops'] / 1e9 / pf - 1:+.1%})")
         print(line)

@@ -3,6 +3,7 @@ python tools/pmc_parse.py DIR [DIR ...]"""
 import collections
 import csv
 import glob
+import os
 import sys
 
 for d in sys.argv[1:]:
@@ -13,4 +14,4 @@ for d in sys.argv[1:]:
             acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (name, ctr), vals in sorted(acc.items()):
             if any(k in name for k in ("msda", "bias_act")):
-                print(f"{d}: {name[:40]:40s} {ctr:14s} dispatches {len(vals):3d} mean {sum(vals) / len(vals):14.1f}")
+                print(f"{os.path.basename(d.rstrip('/'))}: {name[:40]:40s} {ctr:14s} dispatches {len(vals):3d} mean {sum(vals) / len(vals):14.1f}")
