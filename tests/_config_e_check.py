@@ -87,7 +87,7 @@ def cpu_reference_clip(build_fn, clip, threads, timed_passes=1, warm_frames=2):
     full passes (spatial stage + temporal stage of all T frames, before any rescaling), after a ``warm_frames`` warm-up."""
     from models.clip_inference import ClipRunner
     frames = clip.shape[0]
-    with cpu_operators(threads):
+    with cpu_operators(threads), torch.no_grad():
         model = build_fn("cpu", frames - 1)
         runner = ClipRunner(model, micro_batch=1)
         if warm_frames:

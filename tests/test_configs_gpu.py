@@ -202,7 +202,7 @@ def _ragged_pair():
 @pytest.mark.timeout(1200)
 def test_padded_batch_at_production_size(fusion, monkeypatch):
     """util/misc.py:338-356 pads a ragged batch; deformable_transformer_single.py:155-177 turns the mask into valid ratios
-    < 1 and a scaled reference grid.  Two images, 800x1333 and 736x1200 (46 x 75 valid tokens of the 50 x 84 map), through
+    < 1 and a scaled reference grid.  Two images, 800x1333 and 736x1200 (46 x 76 valid tokens of the 50 x 84 map), through
     configs B and C: the level-in-LDS MSDA kernel (4200 queries per image >= LEVEL_MIN_QUERIES), the row-masked block-major
     value projection and the scaled grid see a real mask.  The decoder reads the memory through masked attention only, so
     logits and boxes of both images are comparable in full; PostProcess indices outside the tie margin."""
@@ -268,6 +268,6 @@ def test_padded_transvodpp_clip_at_production_size():
     assert (got["logits"].cpu() - want["logits"]).abs().max() < 1e-3
     assert (got["ref_last"].cpu() - want["ref_last"]).abs().max() < 1e-3
     valid = ~torch.nn.functional.interpolate(mask[None].float(), size=(50, 84)).bool()[0].flatten(1)      # stride-16 map
-    assert int(valid[0].sum()) == 46 * 75
+    assert int(valid[0].sum()) == 46 * 76          # nearest-neighbour mask resize: rows 16 i < 736, columns floor(15.87 j) < 1200
     diff = (got["memory"].cpu() - want["memory"]).abs().max(-1)[0]
     assert (diff * valid).max() < 1e-3
