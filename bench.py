@@ -47,8 +47,8 @@ The JSON line also carries
                `fp32_mfma_frac` counts the 3x3 stride-1 convolutions in DIRECT-form flops (what the reference computes),
                `fp32_mfma_frac_executed` in the flops the Winograd kernel executes (1/2.25 of them).
   ms_per_step_p50  median GPU time of a step from HIP events recorded after each step on the stream its last kernel
-               runs on (the tail stream of the clip pipeline, else the current stream; no host sync inside the timed
-               region).
+               runs on (the completion events of the clip pipeline's steps - consecutive completions of one lane divided
+               by the number of lanes -, else events on the current stream; no host sync inside the timed region).
 """
 import argparse
 import json
@@ -176,6 +176,11 @@ def main():
                          "+4 %% frames/s at 32 frames per GPU, +13 %% at 4; 0 = one clip at a time on one stream; 1 = on, the "
                          "default for every N since round 3: the per-kernel roofline durations then come from one extra "
                          "single-stream step)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="independent stream pairs the clip pipeline deals consecutive steps to (ClipRunner(lanes=...): each lane "
+                         "keeps two clips in flight).  0 = by the rank's block: 2 lanes up to 16 frames per step, 1 above "
+                         "(tools/rank_step.py, profiles/r04_rank_step.txt: 4 frames 12.8 -> 11.6 ms, 8 frames 25.2 -> 21.7 ms per "
+                         "step with two lanes; no gain at 32 frames)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
@@ -221,13 +226,20 @@ def main():
     mine = torch.cat(block, 0) if clips > 1 else block[0]          # resident in HBM before timing
     del block
     rank_frames = clips * per_rank                                  # frames a rank runs per step
-    runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap))
+    lanes = a.lanes if a.lanes > 0 else (2 if rank_frames <= 16 else 1)
+    runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes)
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
     # N > 1: the exchange sits on the side stream - how torch.distributed's NCCL backend is meant to be used; exercised on
     # RCCL with one rank (tests/test_clip_shard_gpu.py::test_rccl_call_path_with_one_rank) and with two ranks over gloo
     pipelined = n_micro == 1 and a.pipeline >= 1
-    step = (lambda: runner.submit(mine, clips=clips)) if pipelined else (lambda: runner(mine, clips=clips))
+    dones = []                                                      # completion events of the pipelined steps (HIP events)
+
+    def step():
+        if pipelined:
+            dones.append(runner.submit(mine, clips=clips)[1])
+        else:
+            runner(mine, clips=clips)
 
     def barrier():
         if world > 1:
@@ -238,19 +250,26 @@ def main():
         step()
     barrier()
     ops.profile_start()                                            # kernels stamp their own begin/end events
+    # step marks without a host sync: with the clip pipeline the completion event of every step (recorded by submit on the
+    # lane's tail stream, where the step's last kernel runs; the first interval starts at the last warm-up step's completion),
+    # else events on the current stream
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    # step marks without a host sync: on the stream a step's LAST kernel runs on - the current stream, or, with the clip
-    # pipeline, the runner's tail stream (the current stream is idle there and its events would complete at once)
-    mark_stream = runner._streams[device][1] if pipelined and device in runner._streams else torch.cuda.current_stream(device)
+    first_timed = len(dones)
     t0 = time.perf_counter()
-    marks[0].record(mark_stream)
+    if not pipelined:
+        marks[0].record(torch.cuda.current_stream(device))
     for i in range(a.steps):
         step()
-        marks[i + 1].record(mark_stream)
+        if not pipelined:
+            marks[i + 1].record(torch.cuda.current_stream(device))
     barrier()
     dt = time.perf_counter() - t0
     launches = ops.profile_stop()
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    stride = 1
+    if pipelined:       # consecutive completions on ONE lane (one stream: ordered) are `lanes` steps apart
+        stride = lanes
+        marks = dones[max(first_timed - lanes, 0):]
+    step_ms = sorted(marks[i].elapsed_time(marks[i + stride]) / stride for i in range(len(marks) - stride)) or [dt / a.steps * 1e3]
     timed_region_launches = None
     if overlapped or pipelined:
         # In the timed region the MSDA kernel shares the CUs with the other stream's convolutions, so
@@ -380,7 +399,7 @@ def main():
                        "micro_batch": min(a.micro_batch, rank_frames),
                        "parallelism": f"every clip frame-sharded x{world} ({per_rank} frames/GPU), {clips} clip(s) per step, "
                                       f"1 all-gather of the reference query sets per step",
-                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined},
+                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined, "pipeline_lanes": lanes if pipelined else 0},
             "roofline": roof,
             "roofline_kernels": kernels,
             "e2e": {"hbm_frac": round(fps / world * BYTES_PER_FRAME / HBM_PEAK, 4),

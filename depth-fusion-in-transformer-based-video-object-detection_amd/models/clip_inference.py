@@ -37,7 +37,7 @@ from .fused import enable_fused_inference
 class ClipRunner:
     MIN_OVERLAP_BATCHES = 3
 
-    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True, gather_on_one_rank=False):
+    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True, gather_on_one_rank=False, lanes=1):
         """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode.
         fused: use the GPU-only fused inference routes (models/fused.py); default = model is on a GPU.
         overlap: on a GPU, run the backbones of micro-batch i+1 on one HIP stream while the transformer
@@ -46,9 +46,17 @@ class ClipRunner:
         MIN_OVERLAP_BATCHES micro-batches (measured, tools/rank_step.py: 4 micro-batches of 8 frames
         143.3 -> 133.1 ms, 2 micro-batches 72.8 -> 74.1 ms).
         gather_on_one_rank: run the collective of ``exchange`` although the group has one rank (RCCL's call path on a
-        one-GPU box); a one-rank group skips it otherwise."""
+        one-GPU box); a one-rank group skips it otherwise.
+        lanes: independent stream pairs ``submit`` deals consecutive clips to, round-robin (each lane keeps two clips in
+        flight).  A rank that owns few frames of a clip runs kernels that leave CUs idle (partial last rounds of tiles,
+        the 300-query tail): with two lanes the 4-frame rank step of an 8-GPU run takes 11.6 ms instead of 12.8 (14.6 on one
+        stream), the 8-frame step 21.7 instead of 25.2 (profiles/r04_rank_step.txt); three lanes add nothing, and neither do
+        two at 32 frames per rank."""
         self.model = model
         self.gather_on_one_rank = gather_on_one_rank
+        self.lanes = max(1, int(lanes))
+        self._next_lane = 0
+        self._lane_warm = set()
         self.micro_batch = micro_batch
         self.group = group
         self.overlap = overlap
@@ -234,16 +242,23 @@ class ClipRunner:
 
         -> (outputs, done): ``outputs`` as ``__call__``; they are valid once ``done`` (a HIP event) has
         completed - ``done.synchronize()``, ``torch.cuda.current_stream().wait_event(done)`` or a device
-        synchronize.  At most two clips are in flight; a third submit waits for the oldest."""
+        synchronize.  At most two clips are in flight per lane (``lanes`` of the constructor: consecutive clips go to the
+        lanes round-robin); a further submit on a full lane waits for that lane's oldest clip."""
         if not frames.is_cuda:
             out = self(frames, mask, clips)
             return out, None
         dev = frames.device
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
-        if dev not in self._streams:
-            self._streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        s_back, s_tail = self._streams[dev]
-        inflight = self.__dict__.setdefault("_inflight", [])
+        lane = self._next_lane % self.lanes
+        self._next_lane += 1
+        key = (dev, lane)
+        if key not in self._streams:
+            # (the first lane is also filed under the device alone: the pair frames_forward's two-stream schedule uses)
+            self._streams[key] = self._streams[dev] if lane == 0 and dev in self._streams else (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            if lane == 0:
+                self._streams[dev] = self._streams[key]
+        s_back, s_tail = self._streams[key]
+        inflight = self.__dict__.setdefault("_inflight", {}).setdefault(key, [])
         while inflight and inflight[0][-1].query():
             inflight.pop(0)
         if len(inflight) >= 2:
@@ -261,11 +276,16 @@ class ClipRunner:
                 all_ref, all_logits = self.exchange(local["ref"], local["logits"], clips)
                 out = self.temporal_forward(local, all_ref, all_logits, first_frame=rank * (frames.shape[0] // clips),
                                             clips=clips)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=True)
                 done.record(s_tail)
         finally:
             self.overlap = saved_overlap
         inflight.append((frames, staged, local, out, done))           # cross-stream tensors stay referenced until done
+        if key not in self._lane_warm:
+            # a lane's first clip completes before the next lane starts: the small tensors built once and shared by all lanes
+            # (index tables, mask-derived positions: self._cached, util/memo.py) are then complete for every later reader
+            self._lane_warm.add(key)
+            done.synchronize()
         return out, done
 
 

@@ -83,18 +83,24 @@ for F_, mb, ov in eval(CASES) if CASES else [(32, 8, False), (32, 8, True), (16,
 # clips as a stream at the rank's block size (ClipRunner.submit: the tail of step k on a second HIP stream beside the backbones
 # of step k + 1) - what `bench.py --pipeline 2` does for N > 1; the exchange is stood in by repeating the rank's own query sets
 if os.environ.get("PIPE", "0") == "1":
-    for F_ in (4, 8, 16):
-        x = clip[:F_].to(dev)
-        runner = ClipRunner(model, micro_batch=F_, overlap=False)
-        rep = T // F_
-        runner.exchange = lambda ref, logits, clips=1, rep=rep: (ref.repeat(rep, 1, 1), logits.repeat(rep, 1, 1))
-        for _ in range(3):
-            runner.submit(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 8
-        for _ in range(n):
-            runner.submit(x)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        print(f"pipelined: frames/rank {F_:2d} (N={T // F_} GPUs): {dt * 1e3:7.2f} ms/step -> {T / dt:7.1f} frames/s whole job", flush=True)
+    # RUNNERS="1,2,3": that many independent ClipRunner pipelines (2 HIP streams each) fed round-robin - more clips in flight
+    for R in eval("[" + os.environ.get("RUNNERS", "1") + "]"):
+        for F_ in eval(os.environ.get("PIPE_FRAMES", "(4, 8, 16)")):
+            x = clip[:F_].to(dev)
+            rep = T // F_
+            runners = []
+            for _ in range(R):
+                runner = ClipRunner(model, micro_batch=F_, overlap=False)
+                runner.exchange = lambda ref, logits, clips=1, rep=rep: (ref.repeat(rep, 1, 1), logits.repeat(rep, 1, 1))
+                runners.append(runner)
+            for i in range(3 * R):
+                runners[i % R].submit(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 8 * R
+            for i in range(n):
+                runners[i % R].submit(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            print(f"pipelined x{R}: frames/rank {F_:2d} (N={T // F_} GPUs): {dt * 1e3:7.2f} ms/step -> {T / dt:7.1f} frames/s whole job", flush=True)
+            del runners
