@@ -268,7 +268,22 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
             float *dst = outn + q * out_row;
             *reinterpret_cast<float4 *>(dst) = a0;
             *reinterpret_cast<float4 *>(dst + out_chunk) = a1;
+#if defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 1
+            // timing ablation (tools/level_ablate.py; results are wrong): the tap arithmetic of every query after a thread's
+            // first is skipped - its loads stay - to price what sharing the taps between the 4 octet-workgroups could save
+            if (hn) tp.tb[0] += (int)(raw.lg.x * 0.f + raw.o01.x * 0.f + raw.o23.x * 0.f + raw.r.x * 0.f) + THREADS;
+            if (hn && tp.tb[0] + 3 * WB > PL - 8) tp.tb[0] -= PL / 2;
+#else
             if (hn) tp = make_taps<REFDIM>(raw, lv);
+#endif
+#if defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 2
+            // timing ablation (results are wrong): neighbouring lanes read neighbouring tokens whatever their offsets - no LDS
+            // bank conflict - to price the conflicts that per-query offsets cause
+            if (hn) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) tp.tb[p] = (qn % (S - 8)) + p;
+            }
+#endif
             q = qn;
             have = hn;
         }

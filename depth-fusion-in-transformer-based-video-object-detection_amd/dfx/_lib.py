@@ -44,6 +44,8 @@ SIGNATURES = {
     "dfx_group_norm_f32": [_p, _p, _p, _p, _p, _i, _i, _l, _i, ctypes.c_float, _i, _p],
     # include/dfx_conv.h
     "dfx_conv2d_igemm_f32": [_p, _p, _p, _p, _p] + [_i] * 14 + [_l, _p],
+    "dfx_conv2d_tile_fits": [_i] * 6,
+    "dfx_conv2d_tile_f32": [_p, _p, _p, _p] + [_i] * 13 + [_l, _p],
     "dfx_conv3x3_wino_f32": [_p, _p, _p, _p] + [_i] * 7 + [_p],
     "dfx_wino_weights_f32": [_p, _p, _p, _i, _i, _p],
 }

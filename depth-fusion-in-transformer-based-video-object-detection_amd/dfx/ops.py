@@ -19,6 +19,8 @@ ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 # kernel (A/B measurements).  LEVEL_MIN_QUERIES: below it staging the level costs more than it saves.
 USE_LEVEL_KERNEL = os.environ.get("DFX_MSDA_LEVEL", "1") == "1"
 LEVEL_MIN_QUERIES = 1024
+# convolutions of <= 4 input channels from an LDS-resident input tile (csrc/conv_tile.hip); 0: on the implicit GEMM (A/B runs)
+USE_TILE_CONV = os.environ.get("DFX_TILE_CONV", "1") == "1"
 # msda_fused_forward takes operands in the reference layouts, where the level kernel is slower than the
 # wave-per-query kernel (33 vs 26 us at the encoder geometry): it uses it only when this is set (parity tests).
 LEVEL_ON_REFERENCE_LAYOUTS = False
@@ -569,8 +571,10 @@ def bias_relu_maxpool(x, bias):
 class ConvPlan:
     """One convolution prepared for the hand-written kernels (include/dfx_conv.h): 3x3 / stride 1 / "same"
     convolutions with Ci % 8 == 0 and Co % 64 == 0 run as fused Winograd F(2x2, 3x3) (weights pre-transformed
-    on the GPU by dfx_wino_weights_f32), everything else as an implicit GEMM over a tap table (weights
-    re-ordered [Co, (ky, kx, ci)], K padded to a multiple of 16).  ``scale`` (per output channel, e.g. the
+    on the GPU by dfx_wino_weights_f32), convolutions of at most 4 input channels (the 7x7/2 ResNet stem, the first
+    DFormer convolution) as a direct convolution from an LDS-resident input tile (algo "tile", csrc/conv_tile.hip),
+    everything else as an implicit GEMM over a tap table (weights re-ordered [Co, (ky, kx, ci)], K padded to a
+    multiple of 16; the tile kernel takes the same weights).  ``scale`` (per output channel, e.g. the
     folded FrozenBatchNorm2d factor) is multiplied into the weights; ``bias`` and ``act`` run in the epilogue.
     ``weight`` is [Co, Ci, kh, kw] of an ungrouped convolution with zero padding: callers hand over ``conv.groups`` /
     ``conv.padding_mode`` (or check them) - anything else raises."""
@@ -590,10 +594,12 @@ class ConvPlan:
         self.stride, self.padding, self.dilation, self.act = int(stride), int(padding), int(dilation), ACT[act]
         self.bias = None if bias is None else bias.detach().float().contiguous()
         wino_ok = kh == 3 and kw == 3 and stride == 1 and padding == dilation and Ci % 8 == 0 and Co % 64 == 0
-        self.algo = algo or ("wino" if wino_ok else "igemm")
-        _require(self.algo != "wino" or wino_ok, "ConvPlan: geometry not covered by the Winograd kernel")
-        w = weight.detach().contiguous()
         lib = _lib.load()
+        tile_ok = bool(lib.dfx_conv2d_tile_fits(Ci, Co, kh, kw, int(stride), int(dilation)))
+        self.algo = algo or ("wino" if wino_ok else "tile" if (tile_ok and Ci <= 4 and USE_TILE_CONV) else "igemm")
+        _require(self.algo != "wino" or wino_ok, "ConvPlan: geometry not covered by the Winograd kernel")
+        _require(self.algo != "tile" or tile_ok, "ConvPlan: geometry not covered by the tile kernel")
+        w = weight.detach().contiguous()
         if self.algo == "wino":
             self.u = torch.empty(16 * Co * Ci, dtype=torch.float32, device=w.device)
             sc = None if scale is None else scale.detach().float().contiguous()
@@ -632,7 +638,7 @@ class ConvPlan:
                  "conv: x must be a CUDA fp32 tensor [N,Ci,H,W] (no CPU path)")
         N, _, H, W = x.shape
         # a channel slice of a wider NCHW tensor (x[:, :3] of an RGB-D clip) is read in place by the implicit GEMM
-        sliced = (self.algo == "igemm" and not x.is_contiguous() and x.stride(3) == 1 and x.stride(2) == W
+        sliced = (self.algo in ("igemm", "tile") and not x.is_contiguous() and x.stride(3) == 1 and x.stride(2) == W
                   and x.stride(1) == H * W and x.stride(0) >= self.Ci * H * W)
         image_stride = x.stride(0) if sliced else 0
         if not sliced:
@@ -642,6 +648,8 @@ class ConvPlan:
         step = N
         if self.algo == "wino" and N * self.Ci * H * W >= self.WINO_MAX_ELEMENTS:
             step = max(1, (self.WINO_MAX_ELEMENTS - 1) // (self.Ci * H * W))
+        if self.algo == "tile":           # 32-bit byte offsets over the images of a launch: below 4 GiB per launch
+            step = max(1, min(N, ((1 << 30) - 4) // max(image_stride, self.Ci * H * W)))
         with _on(x.device):
             for n0 in range(0, N, step):
                 n1 = min(N, n0 + step)
@@ -649,6 +657,10 @@ class ConvPlan:
                 if self.algo == "wino":
                     rc = lib.dfx_conv3x3_wino_f32(xs.data_ptr(), self.u.data_ptr(), _ptr(self.bias), ys.data_ptr(), n1 - n0, self.Ci,
                                                   H, W, self.Co, self.dilation, self.act, _stream(x.device))
+                elif self.algo == "tile":
+                    rc = lib.dfx_conv2d_tile_f32(xs.data_ptr(), self.wp.data_ptr(), _ptr(self.bias), ys.data_ptr(), n1 - n0, self.Ci,
+                                                 H, W, self.Co, Ho, Wo, self.Kpad, self.kh, self.kw, self.stride, self.padding,
+                                                 self.act, image_stride, _stream(x.device))
                 else:
                     rc = lib.dfx_conv2d_igemm_f32(xs.data_ptr(), self.wp.data_ptr(), self._ktab(H, W, x.device).data_ptr(),
                                                   _ptr(self.bias), ys.data_ptr(), n1 - n0, self.Ci, H, W, self.Co, Ho, Wo, self.Kpad,

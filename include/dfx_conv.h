@@ -40,6 +40,18 @@ int dfx_conv2d_igemm_f32(const float *x, const float *wp, const int *ktab, const
                          int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
                          int stride, int pad, int dilation, int act, long x_image_stride, void *stream);
 
+/* Direct convolution of FEW input channels (Ci * KH * KW <= 160, Co <= 64, stride 1 or 2, no dilation) from an
+ * LDS-resident input tile: the whole receptive field of a 16 x 16 output tile is staged once and the gathered
+ * [K x pixels] operand of the fp32 MFMA is read from LDS (csrc/conv_tile.hip) - the 7x7/2 ResNet stem
+ * (/root/reference/models/backbone_scratch.py:102-141 -> torchvision resnet conv1) and the first convolution of
+ * the DFormer depth stem (/root/reference/models/dformer_backbone.py:18-71).  Operands as dfx_conv2d_igemm_f32
+ * (same wp [Co, Kpad] in (ky, kx, ci) order, zero padded; no tap table: the kernel derives it).
+ * dfx_conv2d_tile_fits: 1 when a geometry is covered. */
+int dfx_conv2d_tile_fits(int Ci, int Co, int KH, int KW, int stride, int dilation);
+int dfx_conv2d_tile_f32(const float *x, const float *wp, const float *bias, float *y,
+                        int N, int Ci, int H, int W, int Co, int Ho, int Wo, int Kpad, int KH, int KW,
+                        int stride, int pad, int act, long x_image_stride, void *stream);
+
 /* 3x3, stride 1, padding = dilation ("same") convolution by Winograd F(2x2, 3x3) with every stage in one
  * kernel: input tiles are transformed while they are staged into LDS, the 16 element-wise products run as
  * 16 GEMMs [Co x Ci] x [Ci x tiles] on fp32 MFMA, the output transform + bias + activation happen on the

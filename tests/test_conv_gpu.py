@@ -45,6 +45,69 @@ def test_igemm_matches_fp64(N, Ci, Co, H, W, k, stride, pad, dil, act):
     assert (got.double() - want).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
 
 
+TILE = [  # N, Ci, Co, H, W, k, stride, pad, act   (csrc/conv_tile.hip: few input channels, the input tile lives in LDS)
+    (2, 3, 64, 67, 90, 7, 2, 3, None),             # ResNet stem geometry, odd map: partial tiles on both axes
+    (3, 3, 64, 96, 128, 7, 2, 3, "relu"),          # several tiles per image, image boundaries inside the batch
+    (3, 1, 16, 40, 67, 3, 2, 1, "gelu"),           # DFormer stem, first convolution (one K-step, 16 of 32 channel rows)
+    (2, 1, 16, 33, 31, 3, 2, 1, None),
+    (2, 2, 24, 19, 37, 3, 1, 1, "relu"),           # stride 1 (no parity split of the staged rows), Co not a multiple of 8
+    (1, 3, 40, 50, 21, 5, 2, 2, None),             # 5x5/2, K = 75 -> 80, two 32-channel blocks with 24 idle rows
+    (5, 3, 7, 9, 8, 3, 1, 0, None),                # no padding: the output is smaller than the input; tiny maps
+]
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,k,stride,pad,act", TILE)
+def test_tile_kernel_matches_fp64_and_the_implicit_gemm(N, Ci, Co, H, W, k, stride, pad, act):
+    from dfx import ops
+    g = torch.Generator().manual_seed(Ci * 17 + Co + H + k)
+    x = torch.randn(N, Ci, H, W, generator=g).cuda()
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    plan = ops.ConvPlan(w, b, stride, pad, 1, act)
+    assert plan.algo == "tile"
+    got = plan(x)
+    want = _ref(x, w, b, stride, pad, 1, act)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
+    other = ops.ConvPlan(w, b, stride, pad, 1, act, algo="igemm")(x)
+    assert (got - other).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
+    for _ in range(3):                                       # run to run: same bits (double-buffered staging, persistent walk)
+        assert torch.equal(plan(x), got)
+    # without a bias
+    assert (ops.ConvPlan(w, None, stride, pad, 1, None)(x).double() - _ref(x, w, None, stride, pad, 1, None)).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
+
+
+def test_tile_kernel_reads_channel_planes_of_a_wider_clip_in_place():
+    """The stems read the RGB planes / the depth plane of the [T,4,H,W] clip in place (image stride argument)."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(5)
+    clip = torch.randn(3, 4, 70, 101, generator=g).cuda()
+    w3 = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).cuda()
+    w1 = (torch.randn(16, 1, 3, 3, generator=g) / 3.0).cuda()
+    for w, sl, st, pd in ((w3, slice(0, 3), 2, 3), (w1, slice(3, 4), 2, 1)):
+        plan = ops.ConvPlan(w, None, st, pd, 1, "relu")
+        assert plan.algo == "tile"
+        got = plan(clip[:, sl])
+        want = _ref(clip[:, sl].contiguous(), w, None, st, pd, 1, "relu")
+        assert (got.double() - want).abs().max().item() < 6e-5
+
+
+def test_tile_kernel_at_production_size_against_the_implicit_gemm():
+    """800 x 1333 stem and depth-stem convolutions of a 4-frame block: every tile position incl. the ragged right / bottom
+    edges, a persistent walk of 8400 tiles over 512 workgroups."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(6)
+    clip = torch.randn(4, 4, 800, 1333, generator=g).cuda()
+    for Co, sl, k, pd in ((64, slice(0, 3), 7, 3), (16, slice(3, 4), 3, 1)):
+        Ci = sl.stop - sl.start
+        w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).cuda()
+        b = torch.randn(Co, generator=g).cuda()
+        got = ops.ConvPlan(w, b, 2, pd, 1, "relu")(clip[:, sl])
+        ref = ops.ConvPlan(w, b, 2, pd, 1, "relu", algo="igemm")(clip[:, sl])
+        assert got.shape == ref.shape == (4, Co, 400, 667)
+        assert (got - ref).abs().max().item() < 4e-6 * (Ci * k * k) ** 0.5
+
+
 WINO = [  # N, Ci, Co, H, W, dil
     (2, 64, 64, 24, 40, 1),
     (3, 64, 64, 25, 41, 1),        # odd map: edge tiles with one valid row / column

@@ -20,7 +20,7 @@ def load(d):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     for r in csv.DictReader(open(f)):
         t[int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    vals = [v for v in rows.values() if any(s in v["name"] for s in ("gemm_f32", "Cijk", "conv_wino", "conv_igemm"))]
+    vals = [v for v in rows.values() if any(s in v["name"] for s in ("gemm_f32", "Cijk", "conv_wino", "conv_igemm", "conv_tile"))]
     groups = []
     for _, grp in itertools.groupby(vals, key=lambda v: (v["name"], v["grid"])):
         grp = list(grp)
