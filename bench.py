@@ -178,9 +178,9 @@ def main():
                          "single-stream step)")
     ap.add_argument("--lanes", type=int, default=0,
                     help="independent stream pairs the clip pipeline deals consecutive steps to (ClipRunner(lanes=...): each lane "
-                         "keeps two clips in flight).  0 = by the rank's block: 2 lanes up to 16 frames per step, 1 above "
-                         "(tools/rank_step.py, profiles/r04_rank_step.txt: 4 frames 12.8 -> 11.6 ms, 8 frames 25.2 -> 21.7 ms per "
-                         "step with two lanes; no gain at 32 frames)")
+                         "keeps two clips in flight).  0 = 2 lanes for every N - one schedule over the scaling curve "
+                         "(tools/rank_step.py, profiles/r04_rank_step.txt: 4 frames per step 12.8 -> 11.6 ms, 8 frames 25.2 -> 21.7, "
+                         "16 frames 43.2 -> 42.4, 32 frames 82.5 -> 81.8 ms with two lanes; three add nothing)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
@@ -226,7 +226,7 @@ def main():
     mine = torch.cat(block, 0) if clips > 1 else block[0]          # resident in HBM before timing
     del block
     rank_frames = clips * per_rank                                  # frames a rank runs per step
-    lanes = a.lanes if a.lanes > 0 else (2 if rank_frames <= 16 else 1)
+    lanes = a.lanes if a.lanes > 0 else 2
     runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes)
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES

@@ -61,6 +61,7 @@ struct Args {
                           // groups of group_m tile rows, then along the columns of every batch element
     int fast_cblk;        // column-block-major C through the same LDS round trip (set by launch())
     int fast_epi;         // wide epilogue in its lean form (set by launch(): no LayerNorm / GELU / act_first, C and R slices < 2 GiB)
+    long strideBias;      // elements the column bias advances per batch element (wide column blocks run as a batch: dfx_gemm_f32)
 };
 
 __device__ __forceinline__ float activate(float v, int act)      // 1: ReLU, 2: exact (erf) GELU
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
     const float *R = g.R ? g.R + bz * g.strideR : nullptr;
     const unsigned char *mask = g.mask ? g.mask + bz * g.strideMask : nullptr;
     const bool brow = g.bias && g.bias_per_row, bcol = g.bias && !g.bias_per_row;
+    const float *const biasp = g.bias ? g.bias + bz * g.strideBias : nullptr;
     constexpr int CQ = BN / 4;                                 // float4 per tile row
     if constexpr (NTHR % CQ == 0) if (g.wide_epilogue && g.fast_epi) {
         // The lean form of the wide epilogue below (same LDS round trip, same float4 rows).  An ablation that ends the tile
@@ -417,14 +419,14 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
         const unsigned rbase_off = ncol ? ((unsigned)mb * (unsigned)g.ldr + (unsigned)n) * 4u : kPast;
         const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)(((long)(g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : C), 0, (int)(((long)(g.M - 1) * (R ? g.ldr : g.ldc) + g.N) * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.bias ? g.bias : C), 0, g.M * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(biasp ? biasp : C), 0, g.M * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsMask = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(mask ? mask : reinterpret_cast<const unsigned char *>(C)), 0, g.M, 0x00020000);
         const int relu = g.relu;
         auto run = [&](auto bias_kind, auto has_r, auto has_mask) {
             constexpr int BIAS = decltype(bias_kind)::value;          // 0 none, 1 per column, 2 per row
             constexpr bool HAS_R = decltype(has_r)::value, HAS_MASK = decltype(has_mask)::value;
             f32x4 bc = {0.f, 0.f, 0.f, 0.f};
-            if (BIAS == 1 && ncol) bc = *reinterpret_cast<const f32x4 *>(g.bias + n);
+            if (BIAS == 1 && ncol) bc = *reinterpret_cast<const f32x4 *>(biasp + n);
             const bool r_pre = HAS_R && PREFETCH_R && use_rpre;
 #pragma unroll
             for (int p = 0; p < BM / PR; ++p) {
@@ -519,8 +521,8 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
                 const int q = blk * QB + sub, n = n0 + q * 4;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&Ct[row * LDC + q * 4]);
                 const bool ok = m < g.M && n < g.N;
-                if (bcol) v += *reinterpret_cast<const f32x4 *>(g.bias + min(n, g.N - 4));
-                if (brow) v += g.bias[min(m, g.M - 1)];
+                if (bcol) v += *reinterpret_cast<const f32x4 *>(biasp + min(n, g.N - 4));
+                if (brow) v += biasp[min(m, g.M - 1)];
                 if (relu) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) asm("v_max_f32 %0, 0, %1" : "=v"(v[u]) : "v"(v[u]));
@@ -563,8 +565,8 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
                 const int m = m0 + p * PR + row, n = n0 + c4 * 4;
                 if (m >= g.M || n >= g.N) continue;
                 float4 v = *reinterpret_cast<const float4 *>(&Ct[row * LDC + c4 * 4]);
-                if (brow) { const float b = g.bias[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
-                if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (brow) { const float b = biasp[m]; v.x += b; v.y += b; v.z += b; v.w += b; }
+                if (bcol) { const float4 b = *reinterpret_cast<const float4 *>(biasp + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 if (g.relu && g.act_first) { v.x = activate(v.x, g.relu); v.y = activate(v.y, g.relu); v.z = activate(v.z, g.relu); v.w = activate(v.w, g.relu); }
                 if (PREFETCH_R && use_rpre) { const f32x4 q = rpre[PREFETCH_R ? f0 / 256 : 0]; v.x += q[0]; v.y += q[1]; v.z += q[2]; v.w += q[3]; }
                 else if (R) { const float4 q = *reinterpret_cast<const float4 *>(R + (long)m * g.ldr + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
     for (int j = 0; j < NT; ++j) {
         ncol[j] = n0 + wn * TN + j * 32 + c;
         const int nc = min(ncol[j], g.N - 1);
-        bcolv[j] = bcol ? g.bias[nc] : 0.f;
+        bcolv[j] = bcol ? biasp[nc] : 0.f;
         coff[j] = g.cblk > 0 ? (long)(nc / g.cblk) * g.cblk_stride + nc % g.cblk : (long)nc;
     }
 #pragma unroll
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, min_blocks(BM, BN, WM * WN, BK)) void
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int mc = min(m, g.M - 1);                         // clamped: branch-free loads
-            const float rb = brow ? g.bias[mc] : 0.f;
+            const float rb = brow ? biasp[mc] : 0.f;
             const bool rz = mask ? mask[mc] != 0 : false;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -799,6 +801,18 @@ extern "C" int dfx_gemm_f32(const float *A, const float *A2, long lda, long stri
         return dfx::fail(DFX_EINVAL, "gemm: column-block-major C needs c_block_stride >= M * c_block and no residual");
     if (a_block_stride < 0 || (a_block_stride > 0 && (a_block_stride < (long)M * 4 || (a_block_stride & 3) || A2)))
         return dfx::fail(DFX_EINVAL, "gemm: K-block-major A needs a_block_stride >= 4 * M (a multiple of 4) and no A2");
+    if (c_block >= 128 && c_block % 128 == 0 && N % c_block == 0 && N > c_block && batch == 1 && !b_is_kn && !R && a_block_stride == 0 &&
+        (c_block_stride & 3) == 0 && dfx::aligned16(C) && (!bias || bias_per_row || dfx::aligned16(bias))) {
+        // Wide column blocks ([N / w][M][w] with w a multiple of the tile width: Linears that share their input, stacked along
+        // N, each result a contiguous [M, w] tensor of its own - the decoder layers' value projections): every block is a
+        // product of its own on the same A.  They run as ONE launch over the batch axis - A fixed, W / the column bias / C
+        // advancing per block - in the XCD-aware tile order, which walks the columns of ALL blocks for a group of tile rows
+        // before it moves on: an A panel is read once for the whole stack.
+        Args g{A, A2, lda, 0, B, ldb, (long)c_block * ldb, bias, bias_per_row, nullptr, 0, 0, row_mask, 0, C, (long)c_block, c_block_stride,
+               M, c_block, K, relu, 0, 0, 0, 1, 1, K};
+        g.strideBias = bias_per_row ? 0 : c_block;
+        return choose_and_launch(g, N / c_block, 0, static_cast<hipStream_t>(stream));
+    }
     const int wide = c_block == 0 && (N & 3) == 0 && (ldc & 3) == 0 && (strideC & 3) == 0 && dfx::aligned16(C) &&
                      (!R || ((ldr & 3) == 0 && (strideR & 3) == 0 && dfx::aligned16(R))) &&
                      (!bias || bias_per_row || dfx::aligned16(bias)) && !dfx::tuning().gemm_narrow_epilogue;

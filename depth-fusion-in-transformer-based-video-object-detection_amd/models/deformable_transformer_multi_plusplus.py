@@ -146,6 +146,12 @@ class DeformableTransformer(SpatialTransformerBase):
         # The scores do not change between the rounds and top-k comes back sorted: the picks of a round with a smaller k are
         # a prefix of the picks of the largest one (the reference calls topk on the same ref_prob_concat[:, :, 1] once per round, :530 / :557 / :582; equal scores may come
         # out in another order - as they may between any two topk implementations), so one selection serves all rounds.
+        # the three temporal decoders cross-attend to the same current-frame memory: their value projections in one launch
+        decoders = [getattr(self, f"temporal_decoder{i + 1}") for i in range(len(TOPK_PER_REF))]
+        tdtd_values = None
+        if cur_memory.is_cuda and not torch.is_grad_enabled() and all(len(d.layers) == 1 for d in decoders):
+            from models.ops.modules.ms_deform_attn import project_values
+            tdtd_values = project_values([d.layers[0].cross_attn for d in decoders], cur_memory, None)
         kmax = max(TOPK_PER_REF) * R
         vals_all, idx_all = torch.topk(score, kmax, dim=1)                          # [F,kmax R] in [0, R*Q)
         rows_all = torch.gather(others, 1, idx_all // Q) * Q + idx_all % Q          # rows of the flat pool
@@ -162,8 +168,8 @@ class DeformableTransformer(SpatialTransformerBase):
             else:
                 selected = flat_pool[rows.reshape(-1)].view(F_, k * R, C)
                 cur_hs = tqe(cur_hs, selected)
-            cur_hs, refs = getattr(self, f"temporal_decoder{i + 1}")(
-                cur_hs, cur_reference_out, cur_memory, shapes1, lsi1, ratios, None, None)
+            cur_hs, refs = decoders[i](cur_hs, cur_reference_out, cur_memory, shapes1, lsi1, ratios, None, None,
+                                       values=None if tdtd_values is None else [tdtd_values[i]])
             if i < 2:
                 aux.append({"pred_logits": temp_class_embed_list[i](cur_hs),
                             "pred_boxes": apply_box_head(temp_bbox_embed_list[i], cur_hs, refs)})

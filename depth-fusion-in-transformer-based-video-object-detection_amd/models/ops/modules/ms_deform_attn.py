@@ -14,6 +14,7 @@ signature as the reference.  Two execution routes:
 There is no CPU route: like the reference's op (ms_deform_attn.h:38) it raises on CPU tensors.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -94,14 +95,17 @@ class MSDeformAttn(nn.Module):
         return self._qproj_head
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, post=None):
+                input_padding_mask=None, post=None, value=None):
         """query [N,Lq,C] (or a (tensor, positional_embedding) pair whose sum is the query: the add is
         then fused into the projection GEMM); reference_points [N,Lq,L,2] (or 4: cx,cy,w,h) in [0,1];
         input_flatten [N,sum(H_l*W_l),C]; input_spatial_shapes i64 [L,2]; input_level_start_index
         i64 [L]; input_padding_mask [N,S] True = padding.  -> [N,Lq,C]   (ref :78-117)
         post = (residual, norm[, dropout]): return ``norm(residual + dropout(output))`` instead - what every caller does
         next; on the fused GPU routes, and when the dropout is the identity (eval mode), the add and the LayerNorm ride in
-        output_proj's GEMM epilogue (dfx.ops.linear(norm=...))."""
+        output_proj's GEMM epilogue (dfx.ops.linear(norm=...)).
+        value [N,S,C]: ``value_proj(input_flatten)`` with the padded tokens already zeroed, when the caller projected the
+        values of several layers that share ``input_flatten`` in one launch (``project_values``); the single-level
+        many-query route (block-major operands) ignores it."""
         N, Lq, _ = (query[0] if isinstance(query, tuple) else query).shape
         _, S, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -139,8 +143,9 @@ class MSDeformAttn(nn.Module):
             # caller's ``src + pos`` add when handed over as a (src, pos) pair), fused sampling
             q, q_add = query if isinstance(query, tuple) else (query, None)
             w, b = self._qproj_params()
-            value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
-                                row_mask=input_padding_mask)
+            if value is None:
+                value = _ops.linear(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias,
+                                    row_mask=input_padding_mask)
             qproj = _ops.linear(q.contiguous(), w, b, add=None if q_add is None else q_add.contiguous())
             sampled = _ops.msda_fused_forward(value.view(N, S, M, D), input_spatial_shapes, input_level_start_index,
                                               reference_points, qproj, L, P)
@@ -152,9 +157,10 @@ class MSDeformAttn(nn.Module):
         if isinstance(query, tuple):
             query = query[0] + query[1]
 
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        if value is None:
+            value = self.value_proj(input_flatten)
+            if input_padding_mask is not None:
+                value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, S, M, D)
 
         offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
@@ -178,3 +184,31 @@ class MSDeformAttn(nn.Module):
                                                        locations, weights, self.im2col_step)
         out = self.output_proj(sampled)
         return apply_post(post, out)
+
+
+_STACK_VALUES = os.environ.get("DFX_VALUE_STACK", "1") == "1"          # 0: every layer projects its own values (A/B runs)
+
+
+def project_values(attns, input_flatten, input_padding_mask=None):
+    """``value_proj`` of several MSDeformAttn modules over the SAME ``input_flatten`` [N,S,C] in ONE GEMM launch (weights
+    stacked along N, every result a contiguous [N,S,C] tensor of its own: dfx.ops.linear(col_block=C)) with the padded tokens
+    zeroed - the six decoder layers of a frame read one memory, the three temporal decoders one current-frame memory
+    (/root/reference/models/deformable_transformer_single.py:703-748, deformable_transformer_multi_plusplus.py:560-599 each
+    project it on their own: the same products, the input read once instead of once per layer).
+    -> list of value tensors for ``MSDeformAttn.forward(value=...)``, or None where the fused GPU route does not apply."""
+    first = attns[0]
+    C = first.d_model
+    if (not _STACK_VALUES or len(attns) < 2 or torch.is_grad_enabled() or not input_flatten.is_cuda or input_flatten.dtype != torch.float32
+            or C % 128 != 0 or any(a.d_model != C or a.value_proj.weight.dtype != torch.float32 or a.value_proj.bias is None
+                                   or a.value_proj.weight.device != input_flatten.device for a in attns)):
+        return None
+    key = tuple((a.value_proj.weight.data_ptr(), a.value_proj.weight._version, a.value_proj.bias.data_ptr(), a.value_proj.bias._version)
+                for a in attns)
+    cache = getattr(first, "_value_stack", None)
+    if cache is None or cache[0] != key:
+        cache = (key, torch.cat([a.value_proj.weight for a in attns], 0).contiguous(),
+                 torch.cat([a.value_proj.bias for a in attns], 0).contiguous())
+        first._value_stack = cache
+    N, S, _ = input_flatten.shape
+    out = _ops.linear(input_flatten.contiguous(), cache[1], cache[2], row_mask=input_padding_mask, col_block=C)   # [n, N*S, C]
+    return [out[i].view(N, S, C) for i in range(len(attns))]

@@ -20,6 +20,7 @@ from torch import nn
 from models.fused import Linear, apply_post
 
 from models.ops.modules import MSDeformAttn
+from models.ops.modules.ms_deform_attn import project_values
 from util.memo import memo_on
 from util.misc import inverse_sigmoid
 
@@ -352,11 +353,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                 dropout=self.dropout4)
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
-                src_padding_mask=None):
+                src_padding_mask=None, value=None):
+        """value: this layer's ``cross_attn.value_proj(src)`` when the decoder projected all its layers' values in one
+        launch (``project_values``)."""
         qk = _add_pos(tgt, query_pos)
         tgt = _mha(self.self_attn, qk, qk, tgt, post=(tgt, self.norm2, self.dropout2))
         tgt = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                              level_start_index, src_padding_mask, post=(tgt, self.norm1, self.dropout1))
+                              level_start_index, src_padding_mask, post=(tgt, self.norm1, self.dropout1), value=value)
         return self.forward_ffn(tgt)
 
 
@@ -397,13 +400,17 @@ class DeformableTransformerDecoder(nn.Module):
         return new.sigmoid().detach()
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
-                query_pos=None, src_padding_mask=None):
+                query_pos=None, src_padding_mask=None, values=None):
+        """values: the layers' value projections of ``src`` when the caller already has them (the three temporal decoders of
+        TransVOD++ share one memory); else all layers' are projected here in one launch (GPU inference)."""
         output = tgt
         inter, inter_refs = [], []
+        if values is None and _gpu_inference(src):
+            values = project_values([layer.cross_attn for layer in self.layers], src, src_padding_mask)
         for lid, layer in enumerate(self.layers):
             ref_in = _scale_reference(reference_points, src_valid_ratios)
             output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
-                           src_padding_mask)
+                           src_padding_mask, **({} if values is None else {"value": values[lid]}))
             reference_points = self._refine(lid, output, reference_points)
             if self.return_intermediate:
                 inter.append(output)

@@ -26,7 +26,11 @@
  *   C   [M,N] row-major, ldc; or, with c_block = w > 0, column-block-major: element (m, n) at
  *       C[(n / w) * c_block_stride + m * w + n % w] - the layout the level-in-LDS MSDA kernel
  *       (dfx_msda.h) reads: value_proj output as [32 channel octets][tokens][8], the joint
- *       sampling_offsets / attention_weights output as [8 heads][queries][12] (no residual then)
+ *       sampling_offsets / attention_weights output as [8 heads][queries][12] (no residual then).
+ *       A wide block (w a multiple of 128, [N,K] operand) stacks Linears that share A: every block is
+ *       a contiguous [M, w] result of its own (the value projections of the six decoder layers over one
+ *       memory, /root/reference/models/deformable_transformer_single.py:703-748); they run as one launch
+ *       that reads an A panel once for the whole stack
  *   relu 0: none, 1: ReLU, 2: exact (erf) GELU (nn.GELU() of the fusion blocks' FFN,
  *       /root/reference/models/deformable_transformer_single.py:379-402)
  * fp32 in, fp32 accumulate (exact fp32 MFMA), fp32 out.  K must be a multiple of 4; A, B rows

@@ -448,3 +448,26 @@ def test_linear_with_layernorm_epilogue_matches_fp64(M, K, act, act_first, res, 
                             else ops.linear(xin, w, b, act=act, residual=r, add=a, x_blocked=blocked),
                             r if (act_first or act is None) else None, norm)
     assert (got - sep).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,n,w,K,masked", [(16800, 6, 256, 256, True), (4200, 3, 256, 256, False), (1200, 3, 512, 256, False),
+                                           (130, 2, 128, 64, True)])
+def test_linear_stack_of_wide_column_blocks(M, n, w, K, masked):
+    """col_block = w, a multiple of 128: n Linears over the same rows stacked along N, one launch, every result a contiguous
+    [M, w] tensor (the decoder layers' value projections, models/ops/modules/ms_deform_attn.py:project_values) - against the
+    n separate Linears and fp64."""
+    from dfx import ops
+    g = torch.Generator().manual_seed(M + n + w)
+    x = torch.randn(M, K, generator=g).cuda()
+    ws = [(torch.randn(w, K, generator=g) / K ** 0.5).cuda() for _ in range(n)]
+    bs = [torch.randn(w, generator=g).cuda() for _ in range(n)]
+    mask = (torch.rand(M, generator=g) > 0.7).cuda() if masked else None
+    out = ops.linear(x, torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), row_mask=mask, col_block=w)
+    assert out.shape == (n, M, w)
+    for i in range(n):
+        alone = ops.linear(x, ws[i], bs[i], row_mask=mask)
+        want = x.double() @ ws[i].double().t() + bs[i].double()
+        if masked:
+            want = want.masked_fill(mask[:, None], 0.0)
+        assert (out[i].double() - want).abs().max().item() < 4e-6 * K ** 0.5
+        assert (out[i] - alone).abs().max().item() < 4e-6 * K ** 0.5
