@@ -181,6 +181,13 @@ def main():
                          "keeps two clips in flight).  0 = 2 lanes for every N - one schedule over the scaling curve "
                          "(tools/rank_step.py, profiles/r04_rank_step.txt: 4 frames per step 12.8 -> 11.6 ms, 8 frames 25.2 -> 21.7, "
                          "16 frames 43.2 -> 42.4, 32 frames 82.5 -> 81.8 ms with two lanes; three add nothing)")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: the clip pipeline replays every rank step as HIP graphs (ClipRunner(graph=True): spatial stage + "
+                         "query/RoI fusion, eager exchange, temporal stage) instead of launching ~1500 kernels from Python - same "
+                         "kernels, bit-equal outputs, host time per step from 10.8 ms to 0.3 ms at 4 frames per rank, where the "
+                         "eager host is 88 %% busy; a lane is then one stream (3 lanes).  -1 (default) = on up to 4 frames per rank and "
+                         "step (an 8-GPU run: 12.3 -> 11.6 ms per step, profiles/r04_rank_step.txt), off above (no gain at 8, "
+                         "eager 1 %% ahead at 32)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
@@ -226,8 +233,9 @@ def main():
     mine = torch.cat(block, 0) if clips > 1 else block[0]          # resident in HBM before timing
     del block
     rank_frames = clips * per_rank                                  # frames a rank runs per step
-    lanes = a.lanes if a.lanes > 0 else 2
-    runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes)
+    use_graph = bool(a.graph) if a.graph >= 0 else (rank_frames <= 4 and a.pipeline >= 1)
+    lanes = a.lanes if a.lanes > 0 else (3 if use_graph else 2)
+    runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes, graph=use_graph)
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
     # N > 1: the exchange sits on the side stream - how torch.distributed's NCCL backend is meant to be used; exercised on
@@ -246,6 +254,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if pipelined:             # set-up, not steps: every lane's streams / tables / HIP graphs exist before the W warm-up steps
+        for _ in range(lanes):
+            step()
+        barrier()
+        dones.clear()
     for _ in range(a.warmup):
         step()
     barrier()
@@ -399,7 +412,8 @@ def main():
                        "micro_batch": min(a.micro_batch, rank_frames),
                        "parallelism": f"every clip frame-sharded x{world} ({per_rank} frames/GPU), {clips} clip(s) per step, "
                                       f"1 all-gather of the reference query sets per step",
-                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined, "pipeline_lanes": lanes if pipelined else 0},
+                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined, "pipeline_lanes": lanes if pipelined else 0,
+                       "hip_graphs": use_graph and pipelined and bool(runner._graph_slots) and all(v is not False for v in runner._graph_slots.values())},
             "roofline": roof,
             "roofline_kernels": kernels,
             "e2e": {"hbm_frac": round(fps / world * BYTES_PER_FRAME / HBM_PEAK, 4),

@@ -37,7 +37,7 @@ from .fused import enable_fused_inference
 class ClipRunner:
     MIN_OVERLAP_BATCHES = 3
 
-    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True, gather_on_one_rank=False, lanes=1):
+    def __init__(self, model, micro_batch=4, group=None, fused=None, overlap=True, gather_on_one_rank=False, lanes=1, graph=False):
         """model: models.deformable_detr_multi_plusplus.DeformableDETR in eval mode.
         fused: use the GPU-only fused inference routes (models/fused.py); default = model is on a GPU.
         overlap: on a GPU, run the backbones of micro-batch i+1 on one HIP stream while the transformer
@@ -51,10 +51,17 @@ class ClipRunner:
         flight).  A rank that owns few frames of a clip runs kernels that leave CUs idle (partial last rounds of tiles,
         the 300-query tail): with two lanes the 4-frame rank step of an 8-GPU run takes 11.6 ms instead of 12.8 (14.6 on one
         stream), the 8-frame step 21.7 instead of 25.2 (profiles/r04_rank_step.txt); three lanes add nothing, and neither do
-        two at 32 frames per rank."""
+        two at 32 frames per rank.
+        graph: ``submit`` replays the rank step as HIP graphs (one per lane and input shape: the spatial stage + query/RoI
+        fusion, then - after the eager exchange when the clip is sharded - the temporal stage) instead of launching its ~1500
+        kernels from Python: the same kernels and bit-equal outputs, the host side of a 4-frame step drops from ~9 ms to
+        well under 1 ms (8 ranks share one host).  A lane is then ONE stream with one clip in flight; use 3-4 lanes.  Masked
+        (padded) clips take the eager route."""
         self.model = model
         self.gather_on_one_rank = gather_on_one_rank
         self.lanes = max(1, int(lanes))
+        self.graph = bool(graph)
+        self._graph_slots = {}
         self._next_lane = 0
         self._lane_warm = set()
         self.micro_batch = micro_batch
@@ -247,6 +254,8 @@ class ClipRunner:
         if not frames.is_cuda:
             out = self(frames, mask, clips)
             return out, None
+        if self.graph and mask is None:
+            return self._submit_graph(frames, clips)
         dev = frames.device
         rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
         lane = self._next_lane % self.lanes
@@ -287,6 +296,95 @@ class ClipRunner:
             self._lane_warm.add(key)
             done.synchronize()
         return out, done
+
+
+    # ---- the same as HIP graphs ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _submit_graph(self, frames, clips=1):
+        dev = frames.device
+        sharded = dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.gather_on_one_rank)
+        sharded = sharded or "exchange" in self.__dict__          # (an instance-level stand-in for the exchange: tools/rank_step.py)
+        rank = dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+        first = rank * (frames.shape[0] // clips)
+        lane = self._next_lane % self.lanes
+        self._next_lane += 1
+        skey = (str(dev), lane)
+        if skey not in self._streams:
+            self._streams[skey] = torch.cuda.Stream(dev)
+        stream = self._streams[skey]
+        key = (skey, tuple(frames.shape), frames.dtype, clips, sharded)
+        slot = self._graph_slots.get(key)
+        cur = torch.cuda.current_stream(dev)
+        saved_overlap, self.overlap = self.overlap, False
+        try:
+            if slot is None:
+                slot = self._capture_slot(frames, clips, first, sharded, stream, cur)
+                self._graph_slots[key] = slot
+            if slot is False:                                             # capture failed once (reported then): eager route
+                self.overlap = saved_overlap
+                saved_graph, self.graph = self.graph, False
+                self._next_lane -= 1
+                try:
+                    return self.submit(frames, None, clips)
+                finally:
+                    self.graph = saved_graph
+            stream.wait_stream(cur)                                       # the caller's frames
+            with torch.cuda.stream(stream):
+                slot["in"].copy_(frames, non_blocking=True)
+                slot["g1"].replay()
+                if sharded:
+                    ar, al = self.exchange(slot["local"]["ref"], slot["local"]["logits"], clips)
+                    slot["ref"].copy_(ar)
+                    slot["logits"].copy_(al)
+                    slot["g2"].replay()
+                # the graph's own output buffers are overwritten by the lane's next clip: hand out copies
+                o = slot["out"]
+                out = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o.items()}
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(stream)
+        finally:
+            self.overlap = saved_overlap
+        hold = self.__dict__.setdefault("_ginflight", {}).setdefault(skey, [])
+        hold.append((frames, done))                                       # the input stays referenced until its copy has run
+        while len(hold) > 2:
+            hold.pop(0)
+        return out, done
+
+
+    def _capture_slot(self, frames, clips, first, sharded, stream, cur):
+        """Graphs of one (lane, input shape): eager passes on the lane's stream first - every table built once (self._cached,
+        util/memo.py), every kernel's one-time set-up done: a capture must not meet a blocking copy - then the capture(s), into
+        one memory pool.  Other threads (the collective backend's watchdog) may call the runtime meanwhile: thread-local
+        capture mode.  -> the slot, or False when the capture failed (said once on stderr; the caller runs eagerly)."""
+        import sys
+        try:
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    local = self._tail_block(self._encode_block(frames))
+                    ar, al = self.exchange(local["ref"], local["logits"], clips)
+                    self.temporal_forward(local, ar, al, first_frame=first, clips=clips)
+            stream.synchronize()
+            slot = {"in": frames.clone()}
+            slot["g1"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(slot["g1"], stream=stream, capture_error_mode="thread_local"):
+                local = self._tail_block(self._encode_block(slot["in"]))
+                if not sharded:
+                    slot["out"] = self.temporal_forward(local, local["ref"], local["logits"], first_frame=first, clips=clips)
+            slot["local"] = local
+            if sharded:
+                with torch.cuda.stream(stream):
+                    ar, al = self.exchange(local["ref"], local["logits"], clips)
+                    slot["ref"], slot["logits"] = ar.clone(), al.clone()
+                stream.synchronize()
+                slot["g2"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(slot["g2"], stream=stream, pool=slot["g1"].pool(), capture_error_mode="thread_local"):
+                    slot["out"] = self.temporal_forward(local, slot["ref"], slot["logits"], first_frame=first, clips=clips)
+            return slot
+        except RuntimeError as e:                                          # (a failed capture leaves the eager route intact)
+            print(f"ClipRunner: HIP-graph capture failed ({str(e).splitlines()[0][:200]}); this shape runs eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize(frames.device)
+            return False
 
 
 class VideoStream:

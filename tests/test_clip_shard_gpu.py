@@ -102,18 +102,18 @@ def test_two_stream_schedule_gives_identical_outputs():
         torch.backends.cudnn.deterministic = saved
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 3])
-def test_clip_pipeline_submit_matches_call(lanes):
+@pytest.mark.parametrize("lanes,graph", [(1, False), (2, False), (3, False), (1, True), (3, True)])
+def test_clip_pipeline_submit_matches_call(lanes, graph):
     """ClipRunner.submit (backbones of clip k+1 on one HIP stream beside the tail of clip k on another, at
-    most two clips in flight per lane; ``lanes`` stream pairs dealt round-robin) returns what __call__ returns, for a stream
-    of different clips."""
+    most two clips in flight per lane; ``lanes`` stream pairs dealt round-robin; ``graph``: every step a HIP-graph replay)
+    returns what __call__ returns, for a stream of different clips - bit for bit."""
     from models.clip_inference import ClipRunner
     model = _build()
     clips = [torch.randn(4, 4, 64, 96, generator=torch.Generator().manual_seed(40 + i)).cuda() for i in range(9)]
     saved = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True         # see test_two_stream_schedule_gives_identical_outputs
     try:
-        runner = ClipRunner(model, micro_batch=4, lanes=lanes)
+        runner = ClipRunner(model, micro_batch=4, lanes=lanes, graph=graph)
         want = [runner(c) for c in clips]
         torch.cuda.synchronize()
         handles = [runner.submit(c) for c in clips]   # queued back to back, nothing waited for in between
@@ -158,7 +158,11 @@ def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline, l
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["rccl"] == {"backend": "gloo", "world": 2}
     assert line["config"]["frames_per_gpu_per_clip"] == 2 and line["roofline"]["bound"] == "mfma"
-    assert line["config"]["clip_pipeline"] == (pipeline >= 1) and line["config"]["pipeline_lanes"] == (2 if pipeline else 0)
+    # 2 frames per rank and step (<= 4): the pipelined steps are HIP-graph replays on 3 lanes, the exchange between the two
+    # graphs of a step goes over the process group eagerly; the N-clips-per-step mode (4 frames per rank) too
+    graphs = pipeline >= 1
+    assert line["config"]["clip_pipeline"] == (pipeline >= 1) and line["config"]["pipeline_lanes"] == (3 if pipeline else 0)
+    assert line["config"]["hip_graphs"] == graphs
     assert line["ms_per_step_p50"] > 0
     if clips_per_step == 0:
         assert line["scaling"] == "weak" and line["config"]["clips_per_step"] == 2 and line["config"]["frames_per_gpu"] == 4

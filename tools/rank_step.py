@@ -90,17 +90,22 @@ if os.environ.get("PIPE", "0") == "1":
             rep = T // F_
             runners = []
             for _ in range(R):
-                runner = ClipRunner(model, micro_batch=F_, overlap=False)
+                runner = ClipRunner(model, micro_batch=F_, overlap=False, lanes=int(os.environ.get("LANES", "1")),
+                                    graph=os.environ.get("GRAPH", "0") == "1")
                 runner.exchange = lambda ref, logits, clips=1, rep=rep: (ref.repeat(rep, 1, 1), logits.repeat(rep, 1, 1))
                 runners.append(runner)
-            for i in range(3 * R):
+            L = int(os.environ.get("LANES", "1"))
+            for i in range(3 * R * L):
                 runners[i % R].submit(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n = 8 * R
+            n = 8 * R * L
             for i in range(n):
                 runners[i % R].submit(x)
+            th = (time.perf_counter() - t0) / n
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
-            print(f"pipelined x{R}: frames/rank {F_:2d} (N={T // F_} GPUs): {dt * 1e3:7.2f} ms/step -> {T / dt:7.1f} frames/s whole job", flush=True)
+            mode = "graph" if os.environ.get("GRAPH", "0") == "1" else "eager"
+            print(f"pipelined x{R} ({mode}, {L} lane(s) per runner): frames/rank {F_:2d} (N={T // F_} GPUs): {dt * 1e3:7.2f} ms/step -> "
+                  f"{T / dt:7.1f} frames/s whole job; host {th * 1e3:5.2f} ms/step in submit", flush=True)
             del runners
