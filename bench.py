@@ -69,13 +69,21 @@ import torch.distributed as dist  # noqa: E402
 torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
 
-# HBM-side traffic of one MSDA encoder-geometry launch, per frame, from the PMC passes committed in
-# profiles/r03_pmc_msda_level.md: (2 x FETCH_SIZE + WRITE_SIZE) KiB at N = 32 frames, the
-# factor 2 being the gfx950 FETCH_SIZE correction calibrated in the same run
-MSDA_TRAFFIC_PER_FRAME = (2 * 96670.5 + 134400.0) * 1024 / 32
-# fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE + WRITE_SIZE) per kernel family and 32-frame step, and the
-# family's launches per step, from the PMC passes over this workload committed in profiles/r03_pmc_traffic.md
-FAMILY_TRAFFIC_PER_STEP = {"gemm": (98964.8e6, 204), "wino": (18930.5e6, 28), "igemm": (33212.0e6, 9)}
+# Fabric-side traffic (HBM + Infinity Cache: 2 x FETCH_SIZE - the gfx950 correction - + WRITE_SIZE, separate PMC passes) per
+# kernel family and 32-frame step: profiles/pmc_traffic.json, written by tools/pmc_traffic.py from the PMC passes over this
+# workload (tools/profile_round_a.sh); counters cannot be read inside a timed run, so the line quotes the committed passes
+with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as _fh:
+    _PMC = json.load(_fh)["families"]
+
+
+def _family_traffic(name):
+    f = _PMC[name]
+    return f["fetch_bytes_per_step"] + f["write_bytes_per_step"], f["launches_per_step"]
+
+
+FAMILY_TRAFFIC_PER_STEP = {"gemm": _family_traffic("gemm_f32_kernel"), "wino": _family_traffic("conv_wino_kernel"),
+                           "igemm": _family_traffic("conv_igemm_kernel")}
+MSDA_TRAFFIC_PER_FRAME = _family_traffic("msda_fused_level")[0] / _family_traffic("msda_fused_level")[1] / 32
 
 # per-frame algorithmic work of config E in all-current mode and the one-pass bytes of the kernel families: generated by
 # tools/algorithmic_work.py (a walk over the built model at 800x1333) into tools/algorithmic_work.json; BASELINE.md
@@ -371,7 +379,7 @@ def main():
                                 if full_size else None),
                     "algorithmic_bytes": int(family_bytes("gemm", rank_frames) / (len(gemm) / steps_profiled)) if full_size else None,
                     "traffic_source": "PMC 2 x FETCH_SIZE + WRITE_SIZE (HBM + Infinity Cache side of L2), average per launch of "
-                                      "the family, profiles/r03_pmc_traffic.md",
+                                      "the family, profiles/pmc_traffic.json (tools/pmc_traffic.py)",
                     "algorithmic_source": "tools/algorithmic_work.py: one-pass bytes of every 1x1 convolution and Linear of a step "
                                           "(inputs + outputs + weights + bottleneck residual reads), average per launch",
                     "launches": len(gemm), "flops_per_launch": wsum / len(gemm), "avg_launch_us": round(tsum / len(gemm) * 1e6, 2),
@@ -387,7 +395,7 @@ def main():
                     "bound": "hbm", "achieved": round(nbytes / mean_t / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(nbytes / mean_t / HBM_PEAK, 4),
                     "traffic": int(MSDA_TRAFFIC_PER_FRAME * min(a.micro_batch, rank_frames)),
-                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/r03_pmc_msda_level.md",
+                    "traffic_source": "PMC FETCH_SIZE/WRITE_SIZE, profiles/pmc_traffic.json",
                     "launches_per_step": round(len(enc) / steps_profiled, 1), "bytes_per_launch": nbytes,
                     "avg_launch_us": round(mean_t * 1e6, 2),
                     "share_of_step": round(mean_t * len(enc) / steps_profiled / step_s, 4)}
