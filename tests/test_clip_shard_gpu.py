@@ -76,6 +76,63 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert torch.equal(top_a, top_b)
 
 
+def _worker_full(rank, world, port, result_path, graph):
+    """Config E at production size on `world` ranks sharing cuda:0 over gloo: the bench's own pipeline (ClipRunner.submit, two
+    lanes or HIP graphs, the exchange on the lane's stream) on three different 32-frame 800x1333 clips."""
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from models.clip_inference import ClipRunner
+        torch.cuda.set_device(0)
+        T = 32
+        per = T // world
+        model = bench.build(torch.device("cuda", 0), T - 1)
+        runner = ClipRunner(model, micro_batch=per, lanes=3 if graph else 2, graph=graph)
+        outs = []
+        for c in range(3):
+            clip = torch.randn(T, 4, 800, 1333, generator=torch.Generator().manual_seed(42 + c))
+            outs.append(runner.submit(clip[rank * per:(rank + 1) * per].cuda()))
+        res = []
+        for out, done in outs:
+            done.synchronize()
+            res.append({k: out[k].cpu() for k in ("pred_logits", "pred_boxes")})
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            torch.save(gathered, result_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("graph", [False, True])
+def test_config_e_sharded_over_two_ranks_at_production_size(tmp_path, graph):
+    """BASELINE.json configs[4] as the N > 1 bench runs it - 32-frame 800x1333 RGB-D clips, 16 frames per rank, one all-gather of
+    the reference query sets per clip, the clip pipeline with two eager lanes / three HIP-graph lanes - on two ranks over gloo
+    (all this box allows: RCCL needs one GPU per rank), against one process running the whole clip: every frame's logits and
+    boxes within 2e-5 (the GEMM tiling depends on the rows per launch), for three clips in flight."""
+    import bench
+    from models.clip_inference import ClipRunner
+    port = 30700 + os.getpid() % 2000 + int(graph)
+    result = str(tmp_path / "sharded_full.pt")
+    mp.spawn(_worker_full, args=(2, port, result, graph), nprocs=2, join=True)
+    sharded = torch.load(result)                      # [rank][clip]{...}
+    model = bench.build(torch.device("cuda", 0), 31)
+    runner = ClipRunner(model, micro_batch=32)
+    for c in range(3):
+        clip = torch.randn(32, 4, 800, 1333, generator=torch.Generator().manual_seed(42 + c))
+        whole = runner(clip.cuda())
+        for k in ("pred_logits", "pred_boxes"):
+            got = torch.cat([sharded[r][c][k] for r in range(2)], 0)
+            assert got.shape == whole[k].shape
+            err = (got - whole[k].cpu()).abs().max().item()
+            assert err < 2e-5, (c, k, err)
+
+
 def test_two_stream_schedule_gives_identical_outputs():
     """overlap=True (backbones of micro-batch i+1 beside the transformer tail of micro-batch i on two HIP
     streams) only changes the schedule: same kernels, same inputs -> the same bits, run after run."""
