@@ -193,9 +193,9 @@ def main():
                     help="1: the clip pipeline replays every rank step as HIP graphs (ClipRunner(graph=True): spatial stage + "
                          "query/RoI fusion, eager exchange, temporal stage) instead of launching ~1500 kernels from Python - same "
                          "kernels, bit-equal outputs, host time per step from 10.8 ms to 0.3 ms at 4 frames per rank, where the "
-                         "eager host is 88 %% busy; a lane is then one stream (3 lanes).  -1 (default) = on up to 4 frames per rank and "
-                         "step (an 8-GPU run: 12.3 -> 11.6 ms per step, profiles/r04_rank_step.txt), off above (no gain at 8, "
-                         "eager 1 %% ahead at 32)")
+                         "eager host is 88 %% busy; a lane is then one stream (3 lanes).  -1 (default) = on for every N > 1 (ranks share "
+                         "a host; 12.3 -> 11.6 ms per 4-frame step, level at 8 and 16 frames: profiles/r04_rank_step.txt), off for "
+                         "one GPU with 32 frames per step (eager 1 %% ahead)")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="(no-op since round 2: no library convolution is left in the path; every kernel is run-to-run deterministic)")
     ap.add_argument("--backend", default="nccl",
@@ -241,7 +241,9 @@ def main():
     mine = torch.cat(block, 0) if clips > 1 else block[0]          # resident in HBM before timing
     del block
     rank_frames = clips * per_rank                                  # frames a rank runs per step
-    use_graph = bool(a.graph) if a.graph >= 0 else (rank_frames <= 4 and a.pipeline >= 1)
+    # graphs by default whenever the clip is sharded (several ranks share one host: 85-88 % of an eager step is Python launch
+    # time at 4-16 frames per rank, profiles/r04_rank_step.txt) or the step is short; one GPU with 32 frames stays eager (1 % ahead)
+    use_graph = bool(a.graph) if a.graph >= 0 else ((world > 1 or rank_frames <= 4) and a.pipeline >= 1)
     lanes = a.lanes if a.lanes > 0 else (3 if use_graph else 2)
     runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes, graph=use_graph)
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
