@@ -270,9 +270,9 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
             *reinterpret_cast<float4 *>(dst + out_chunk) = a1;
 #if defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 1
             // timing ablation (tools/level_ablate.py; results are wrong): the tap arithmetic of every query after a thread's
-            // first is skipped - its loads stay - to price what sharing the taps between the 4 octet-workgroups could save
-            if (hn) tp.tb[0] += (int)(raw.lg.x * 0.f + raw.o01.x * 0.f + raw.o23.x * 0.f + raw.r.x * 0.f) + THREADS;
-            if (hn && tp.tb[0] + 3 * WB > PL - 8) tp.tb[0] -= PL / 2;
+            // first is skipped - its parameter loads stay (consumed by an empty asm) and the gather re-uses the first query's
+            // taps - to price what sharing the taps between the 4 octet-workgroups could save
+            if (hn) asm volatile("" :: "v"(raw.lg.x), "v"(raw.lg.w), "v"(raw.o01.x), "v"(raw.o01.w), "v"(raw.o23.x), "v"(raw.o23.w), "v"(raw.r.x));
 #else
             if (hn) tp = make_taps<REFDIM>(raw, lv);
 #endif

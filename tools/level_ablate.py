@@ -6,8 +6,11 @@ bank conflicts?  Timing ablations (round 4; the outputs of builds 1 and 2 are WR
 Compiles csrc/msda_level.hip three times into libraries of their own (-DDFX_LEVEL_ABLATE=0 / 1 / 2; the shipped libdfx.so
 carries neither ablation), runs the encoder geometry (50 x 84, block-major operands, per-query offsets of `spread` px) for
 N = 32 / 8 / 4 frames, warm (operands in the Infinity Cache) and cold (384 MB written between launches), HIP events per launch.
-  build 1: a thread computes the taps of its first query only (loads of the later queries' parameters kept): upper bound of
-           what handing the taps over from octet 0 to the other three octet-workgroups could save (it saves 3/4 of that)
+  build 1: a thread computes the taps of its first query only (loads of the later queries' parameters kept): meant as the upper
+           bound of what handing the taps over from octet 0 to the other three octet-workgroups could save - INCONCLUSIVE: hipcc
+           spills 28-40 registers in this build (the shipped kernel sits at 125 of 128) and it runs slower than the shipped
+           one; the instruction counts of the shipped ISA stand in: ~150 of the ~233 vector instructions per (query, octet)
+           are tap arithmetic, 64 v_pk_fma_f32 + 32 ds_read_b128 + ~20 are the gather
   build 2: tap addresses replaced by lane-consecutive tokens: no LDS bank conflict"""
 import ctypes
 import os
@@ -35,7 +38,7 @@ for v in (0, 1, 2):
     lib = ctypes.CDLL(so)
     lib.dfx_msda_fused_level_forward_f32.argtypes = [P, P, I, P, P, P, I, I, I, I, P, P]
     libs[v] = lib
-NAMES = {0: "shipped kernel", 1: "taps of a thread's first query only (WRONG results)", 2: "lane-consecutive tap addresses: no bank conflicts (WRONG results)"}
+NAMES = {0: "shipped kernel", 1: "taps of a thread's first query only (WRONG results; spills: inconclusive)", 2: "lane-consecutive tap addresses: no bank conflicts (WRONG results)"}
 torch.manual_seed(0)
 big = torch.empty(96 * 1024 * 1024, device=dev)
 for N in (32, 8, 4):
