@@ -277,8 +277,11 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL
 runner = ClipRunner(model, micro_batch=4, gather_on_one_rank=True)   # run the collective although world == 1
 got = runner(clip)                                                   # all_gather_into_tensor on the current stream
 outs = [runner.submit(clip) for _ in range(3)]                       # ... and on the side stream of the clip pipeline
+grunner = ClipRunner(model, micro_batch=4, gather_on_one_rank=True, lanes=3, graph=True)
+outs += [grunner.submit(clip) for _ in range(7)]                     # ... and between the two HIP graphs of a step, three lanes
 torch.cuda.synchronize()
 dist.barrier()
+assert len(grunner._graph_slots) == 3 and all(isinstance(v, dict) and "g2" in v for v in grunner._graph_slots.values()), "captures fell back"
 for o in [got] + [o for o, _ in outs]:
     for k in ("pred_logits", "pred_boxes"):
         assert torch.equal(o[k], want[k]), k
@@ -290,8 +293,9 @@ print("RCCL_ONE_RANK_OK")
 @pytest.mark.timeout(600)
 def test_rccl_call_path_with_one_rank():
     """The exchange through RCCL itself (backend "nccl") with ONE rank - all this box allows: process-group initialisation on
-    the device, `all_gather_into_tensor` of the packed query sets on the current stream and on the side stream of the clip
-    pipeline (`ClipRunner.submit`), a barrier, bit-equal outputs.  What it cannot show is the transport between GPUs."""
+    the device, `all_gather_into_tensor` of the packed query sets on the current stream, on the side stream of the clip
+    pipeline (`ClipRunner.submit`) and between the two HIP graphs of a graph-mode step (captures with the backend's watchdog
+    thread alive: thread-local capture mode), a barrier, bit-equal outputs.  What it cannot show is the transport between GPUs."""
     import subprocess
     env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(29300 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=550, env=env)
