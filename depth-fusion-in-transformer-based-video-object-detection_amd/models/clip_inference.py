@@ -357,13 +357,15 @@ class ClipRunner:
         one memory pool.  Other threads (the collective backend's watchdog) may call the runtime meanwhile: thread-local
         capture mode.  -> the slot, or False when the capture failed (said once on stderr; the caller runs eagerly)."""
         import sys
+        slot, err = None, None
         try:
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):
-                for _ in range(2):
+                for _ in range(2):              # (every collective of the set-up happens here, before anything can fail)
                     local = self._tail_block(self._encode_block(frames))
                     ar, al = self.exchange(local["ref"], local["logits"], clips)
                     self.temporal_forward(local, ar, al, first_frame=first, clips=clips)
+                pools = (ar.clone(), al.clone()) if sharded else None        # static buffers of the gathered pools
             stream.synchronize()
             slot = {"in": frames.clone()}
             slot["g1"] = torch.cuda.CUDAGraph()
@@ -373,18 +375,24 @@ class ClipRunner:
                     slot["out"] = self.temporal_forward(local, local["ref"], local["logits"], first_frame=first, clips=clips)
             slot["local"] = local
             if sharded:
-                with torch.cuda.stream(stream):
-                    ar, al = self.exchange(local["ref"], local["logits"], clips)
-                    slot["ref"], slot["logits"] = ar.clone(), al.clone()
-                stream.synchronize()
+                slot["ref"], slot["logits"] = pools
                 slot["g2"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(slot["g2"], stream=stream, pool=slot["g1"].pool(), capture_error_mode="thread_local"):
                     slot["out"] = self.temporal_forward(local, slot["ref"], slot["logits"], first_frame=first, clips=clips)
-            return slot
         except RuntimeError as e:                                          # (a failed capture leaves the eager route intact)
-            print(f"ClipRunner: HIP-graph capture failed ({str(e).splitlines()[0][:200]}); this shape runs eagerly", file=sys.stderr, flush=True)
+            err = str(e).splitlines()[0][:200]
             torch.cuda.synchronize(frames.device)
+        ok = err is None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            # one decision for all ranks: a rank replaying graphs and a rank launching eagerly would still issue the same
+            # collectives, but a rank that failed half-way must not be the only one to know
+            flag = torch.tensor([int(ok)], dtype=torch.int32, device=frames.device if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(int(flag.item()))
+        if not ok:
+            print(f"ClipRunner: HIP-graph capture failed ({err or 'on another rank'}); this shape runs eagerly", file=sys.stderr, flush=True)
             return False
+        return slot
 
 
 class VideoStream:

@@ -16,6 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "depth-fusion-in-transformer-based-video-object-detection_amd")
 
 
+def _free_port():
+    """A port nobody holds right now (arithmetic on the pid can meet a port another test of this run left in TIME_WAIT)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _build():
     from models import build_model
     from models.config import transvodpp_args
@@ -56,7 +64,7 @@ def _worker(rank, world, port, result_path):
 
 @pytest.mark.timeout(600)
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     result = str(tmp_path / "sharded.pt")
     mp.spawn(_worker, args=(2, port, result), nprocs=2, join=True)
     sharded = torch.load(result)
@@ -117,7 +125,7 @@ def test_config_e_sharded_over_two_ranks_at_production_size(tmp_path, graph):
     boxes within 2e-5 (the GEMM tiling depends on the rows per launch), for three clips in flight."""
     import bench
     from models.clip_inference import ClipRunner
-    port = 30700 + os.getpid() % 2000 + int(graph)
+    port = _free_port()
     result = str(tmp_path / "sharded_full.pt")
     mp.spawn(_worker_full, args=(2, port, result, graph), nprocs=2, join=True)
     sharded = torch.load(result)                      # [rank][clip]{...}
@@ -197,7 +205,7 @@ def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline, l
     start its two ranks by itself (bench.py:launch_ranks) and give the same line."""
     import json
     import subprocess
-    port = 29700 + (os.getpid() + 7 * (clips_per_step or 3) + 13 * pipeline) % 2000
+    port = _free_port()
     cmd = [sys.executable]
     if launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -297,6 +305,6 @@ def test_rccl_call_path_with_one_rank():
     pipeline (`ClipRunner.submit`) and between the two HIP graphs of a graph-mode step (captures with the backend's watchdog
     thread alive: thread-local capture mode), a barrier, bit-equal outputs.  What it cannot show is the transport between GPUs."""
     import subprocess
-    env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(29300 + os.getpid() % 2000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=550, env=env)
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
