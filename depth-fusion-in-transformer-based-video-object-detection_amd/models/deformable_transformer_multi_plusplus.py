@@ -152,6 +152,17 @@ class DeformableTransformer(SpatialTransformerBase):
         if cur_memory.is_cuda and not torch.is_grad_enabled() and all(len(d.layers) == 1 for d in decoders):
             from models.ops.modules.ms_deform_attn import project_values
             tdtd_values = project_values([d.layers[0].cross_attn for d in decoders], cur_memory, None)
+        # ... and the rounds whose picks outnumber the pool project it instead of the picks (below): those projections of the one
+        # pool in one launch as well
+        tqes = [getattr(self, f"temporal_query_layer{i + 1}") for i in range(len(TOPK_PER_REF))]
+        pooled = [F_ * k * R > flat_pool.shape[0] for k in TOPK_PER_REF]
+        kv_pools = [None] * len(TOPK_PER_REF)
+        if sum(pooled) >= 2 and cur_hs.is_cuda and not torch.is_grad_enabled():
+            from . import fused_mha
+            which = [i for i, on in enumerate(pooled) if on]
+            if all(fused_mha.usable(tqes[i].cross_attn, flat_pool) for i in which) and tqes[0].cross_attn.embed_dim % 64 == 0:
+                for i, kv in zip(which, fused_mha.project_kv_stack([tqes[i].cross_attn for i in which], flat_pool)):
+                    kv_pools[i] = kv
         kmax = max(TOPK_PER_REF) * R
         vals_all, idx_all = torch.topk(score, kmax, dim=1)                          # [F,kmax R] in [0, R*Q)
         rows_all = torch.gather(others, 1, idx_all // Q) * Q + idx_all % Q          # rows of the flat pool
@@ -159,10 +170,10 @@ class DeformableTransformer(SpatialTransformerBase):
             vals, idx, rows = vals_all[:, :k * R], idx_all[:, :k * R], rows_all[:, :k * R]
             picks.append(idx)
             pick_scores.append(vals)
-            tqe = getattr(self, f"temporal_query_layer{i + 1}")
+            tqe = tqes[i]
             # the pool is shared by all current frames: its key / value projections are computed once per round and the picks
             # gather projected rows (F x k*R rows of two Linears become T*Q rows of one: 8x fewer at 32 frames), same values
-            kv_pool = tqe.project_ref_pool(flat_pool) if F_ * k * R > flat_pool.shape[0] else None
+            kv_pool = kv_pools[i] if kv_pools[i] is not None else (tqe.project_ref_pool(flat_pool) if pooled[i] else None)
             if kv_pool is not None:
                 cur_hs = tqe(cur_hs, None, ref_kv=kv_pool[rows.reshape(-1)].view(F_, k * R, 2 * C))
             else:

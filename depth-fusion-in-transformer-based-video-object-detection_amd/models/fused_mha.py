@@ -30,6 +30,21 @@ def project_kv(mha, pool):
     return _ops.linear(pool.contiguous(), mha.in_proj_weight[E:], mha.in_proj_bias[E:])
 
 
+def project_kv_stack(mhas, pool):
+    """``project_kv`` of several attention modules over the SAME pool in one launch (weights stacked along N, every result a
+    contiguous [rows, 2E] tensor: dfx.ops.linear(col_block=2E)) - the three temporal query encoders of TransVOD++ pick from one
+    pool of reference queries.  -> list of [rows, 2E]"""
+    E = mhas[0].embed_dim
+    key = tuple((m.in_proj_weight.data_ptr(), m.in_proj_weight._version, m.in_proj_bias._version) for m in mhas)
+    cache = getattr(mhas[0], "_kv_stack", None)
+    if cache is None or cache[0] != key:
+        cache = (key, torch.cat([m.in_proj_weight[E:] for m in mhas], 0).contiguous(),
+                 torch.cat([m.in_proj_bias[E:] for m in mhas], 0).contiguous())
+        mhas[0]._kv_stack = cache
+    out = _ops.linear(pool.contiguous(), cache[1], cache[2], col_block=2 * E)          # [n, rows, 2E]
+    return [out[i] for i in range(len(mhas))]
+
+
 def forward(mha, q_in, k_in, v_in, post=None, kv=None):
     """mha: nn.MultiheadAttention; q_in [B,Lq,E], k_in / v_in [B,Lk,E] -> [B,Lq,E]
     (= mha(q_in^T, k_in^T, v_in^T)[0]^T of the module; no caller uses the attention weights).
