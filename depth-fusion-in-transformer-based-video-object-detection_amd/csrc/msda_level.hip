@@ -217,7 +217,9 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
 #pragma unroll
             for (int u = 0; u < STAGE_PASSES; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // straight-line, per-lane predicated: all loads in flight at once
+#if !(defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 4)       // (ablation 4, results wrong: the level is never loaded)
                 if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
+#endif
             }
         }
         // ---- parameters and taps of the first query while the value loads fly ----
@@ -252,6 +254,14 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
             const bool hn = qn < qend;
             if (hn) raw = load_raw<REFDIM>(refn + (long)qn * REFDIM, offn + qn * off_stride, lgn + qn * logit_stride);
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#if defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 3
+            // timing ablation (results are wrong): no gather - the taps are computed and kept alive, nothing is read from LDS
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                a0.x += tp.wt[p].x + tp.wb[p].y;
+                a1.x += tp.wt[p].y + tp.wb[p].x + (float)tp.tb[p];
+            }
+#else
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float4 *b0 = org + tp.tb[p];
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
                 fma4(a0, tp.wb[p].y, b0[WB + 1]);
                 fma4(a1, tp.wb[p].y, b1[WB + 1]);
             }
+#endif
             float *dst = outn + q * out_row;
             *reinterpret_cast<float4 *>(dst) = a0;
             *reinterpret_cast<float4 *>(dst + out_chunk) = a1;

@@ -11,7 +11,8 @@ N = 32 / 8 / 4 frames, warm (operands in the Infinity Cache) and cold (384 MB wr
            spills 28-40 registers in this build (the shipped kernel sits at 125 of 128) and it runs slower than the shipped
            one; the instruction counts of the shipped ISA stand in: ~150 of the ~233 vector instructions per (query, octet)
            are tap arithmetic, 64 v_pk_fma_f32 + 32 ds_read_b128 + ~20 are the gather
-  build 2: tap addresses replaced by lane-consecutive tokens: no LDS bank conflict"""
+  build 2: tap addresses replaced by lane-consecutive tokens: no LDS bank conflict
+  build 3: no gather (nothing read from LDS), build 4: no staging loads - how the phases of an item add up"""
 import ctypes
 import os
 import subprocess
@@ -31,14 +32,15 @@ H, W = 50, 84
 S = H * W
 P, I = ctypes.c_void_p, ctypes.c_int
 libs = {}
-for v in (0, 1, 2):
+for v in (0, 1, 2, 3, 4):
     so = os.path.join(tempfile.gettempdir(), f"liblevel_ablate{v}.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-DDFX_LEVEL_ABLATE={v}",
                            "-I" + os.path.join(ROOT, "include"), "-shared", os.path.join(PKG, "csrc", "msda_level.hip"), "-o", so])
     lib = ctypes.CDLL(so)
     lib.dfx_msda_fused_level_forward_f32.argtypes = [P, P, I, P, P, P, I, I, I, I, P, P]
     libs[v] = lib
-NAMES = {0: "shipped kernel", 1: "taps of a thread's first query only (WRONG results; spills: inconclusive)", 2: "lane-consecutive tap addresses: no bank conflicts (WRONG results)"}
+NAMES = {0: "shipped kernel", 1: "taps of a thread's first query only (WRONG results; spills: inconclusive)", 2: "lane-consecutive tap addresses: no bank conflicts (WRONG results)",
+         3: "no gather: staging + tap arithmetic + stores only (WRONG results)", 4: "no staging loads: tap arithmetic + gather + stores only (WRONG results)"}
 torch.manual_seed(0)
 big = torch.empty(96 * 1024 * 1024, device=dev)
 for N in (32, 8, 4):
