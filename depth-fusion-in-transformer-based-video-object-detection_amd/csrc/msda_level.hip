@@ -33,8 +33,7 @@
 
 namespace {
 
-constexpr int THREADS = 1024;
-constexpr int STAGE_PASSES = 10;          // 2 chunks x 5120 tokens / 1024 threads: the LDS cap
+constexpr int STAGE_SLOTS = 10 * 1024;    // 2 chunks x 5120 tokens: the LDS cap (a thread stages STAGE_SLOTS / threads float4)
 constexpr long LDS_CAP = 160 * 1024;
 
 typedef float v2f __attribute__((ext_vector_type(2)));      // v_pk_{mul,add,fma}_f32 operands
@@ -167,9 +166,18 @@ struct LevelArgs {
 // Persistent: the grid is at most one workgroup per CU (146 KB of LDS each) and every workgroup walks the items
 // (frame, head, octet, query slice) b, b + grid, b + 2 grid, ...: workgroup launch, index setup and the zero border are
 // paid once per CU instead of once per item (4 items per CU at 32 frames).
-template <int REFDIM>
+// THREADS / PREFETCH (round 4): <1024, false> is the kernel of rounds 1-3 - stage, barrier, gather, barrier, item after item.  Its
+// phases add up (tools/level_ablate.py, profiles/r04_level_ablate.txt: staging ~35 us, tap arithmetic + parameters + stores
+// ~34 us, gather ~18 us of a 97 us launch at 32 frames), because the 146 KB image leaves no LDS to stage item i + 1 beside the
+// gather of item i.  <512, true> stages through REGISTERS instead: a workgroup of 8 waves has 256 registers per thread, 80 of
+// them hold the next item's level (20 float4 per thread) - its loads are issued in slices inside the gather loop and written
+// to LDS when the gather is done.  Correct (tests/test_msda_gpu.py::test_level_kernel_prefetch_variant) and SLOWER: 125 vs 116 us
+// cold, 105 vs 99 us warm at 32 frames - with half the waves per CU the two compute phases lose what the overlap gains.  Kept
+// as a selectable variant (DFX_LEVEL_VARIANT=1); the default is <1024, false>.
+template <int REFDIM, int THREADS, bool PREFETCH>
 __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
 {
+    constexpr int STAGE_PASSES = STAGE_SLOTS / THREADS;
     const int H = g.H, W = g.W, Lq = g.Lq, PL = g.PL, qsplit = g.qsplit;
     extern __shared__ float4 img[];                 // [2 planes][PL bordered tokens]
     const int tid = threadIdx.x;
@@ -202,25 +210,67 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
     // item -> (frame, head, octet, query slice).  Items go round-robin to the workgroups and the grid is a multiple of 8
     // (or the item count), so the low 3 bits - the head - are fixed per workgroup and the 4 octets (and the query
     // slices) of one (frame, head) stay on one XCD / L2.
+    float4 v[STAGE_PASSES];
+    // staging loads of an item: lane pair = (token, chunk), 32 contiguous bytes per token; straight-line, per-lane
+    // predicated: all loads in flight at once
+    auto issue_stage = [&](int item) {
+        const int head = item & 7, r = item >> 3;
+        const int n = r / per, oct = (r - n * per) & 3;
+        const float *__restrict__ vb = g.value + n * g.ly.value_frame + head * g.ly.value_head + oct * g.ly.value_oct;
+        const float *src = vb + t0 * vs_token + c0 * vs_chunk;
+        const long step = (THREADS / 2) * vs_token;
+#pragma unroll
+        for (int u = 0; u < STAGE_PASSES; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if !(defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 4)       // (ablation 4, results wrong: the level is never loaded)
+            if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
+#endif
+        }
+    };
+    // land the staged level in LDS: (y, x) of the pass's token advance by a constant step, no division
+    auto land = [&]() {
+        const int dy = (THREADS / 2) / W, dx = (THREADS / 2) - dy * W;
+        int y = t0 / W, x = t0 - y * W;
+        int idx = c0 * PL + (y + 1) * WB + x + 1;
+#pragma unroll
+        for (int u = 0; u < STAGE_PASSES; ++u) {
+            if (t0 + u * (THREADS / 2) < S) img[idx] = v[u];
+            x += dx;
+            idx += dy * WB + dx;
+            if (x >= W) { x -= W; idx += 2; }
+        }
+    };
+    // ... and the same loads in slices of SL, one slice per gather iteration (PREFETCH): a wave's vector-memory counter retires
+    // in order, so a wait for the next query's parameters also waits for every OLDER load - the whole image, if it were issued
+    // in one go before the gather (measured: no gain at all).  A slice is issued right AFTER the next query's parameter loads:
+    // that wait does not cover it, the wait one iteration later does, by when the slice has been in flight for a whole
+    // iteration.
+    constexpr int SL = 3, NSL = (STAGE_PASSES + SL - 1) / SL;
+    auto stage_slice = [&](int s, const float *src) {            // s is wave-uniform: a scalar branch per slice
+        const long step = (THREADS / 2) * vs_token;
+#pragma unroll
+        for (int ss = 0; ss < NSL; ++ss) {
+            if (ss != s) continue;
+#pragma unroll
+            for (int u = ss * SL; u < (ss + 1) * SL && u < STAGE_PASSES; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
+            }
+        }
+    };
+    if (PREFETCH && (int)blockIdx.x < g.nitems) issue_stage(blockIdx.x);
     for (int item = blockIdx.x; item < g.nitems; item += gridDim.x) {
         const int head = item & 7, r = item >> 3;
         const int n = r / per, sub = r - n * per;
         const int oct = sub & 3, qs = sub >> 2;
         const int qbeg = qs * qper, qend = min(Lq, qbeg + qper);
-
-        // ---- issue the staging loads: lane pair = (token, chunk), 32 contiguous bytes per token ----
-        const float *__restrict__ vb = g.value + n * g.ly.value_frame + head * g.ly.value_head + oct * g.ly.value_oct;
-        float4 v[STAGE_PASSES];
-        {
-            const float *src = vb + t0 * vs_token + c0 * vs_chunk;
-            const long step = (THREADS / 2) * vs_token;
-#pragma unroll
-            for (int u = 0; u < STAGE_PASSES; ++u) {
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // straight-line, per-lane predicated: all loads in flight at once
-#if !(defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 4)       // (ablation 4, results wrong: the level is never loaded)
-                if (t0 + u * (THREADS / 2) < S) v[u] = *reinterpret_cast<const float4 *>(src + u * step);
-#endif
-            }
+        if (PREFETCH) {
+            // the image of this item came in slice by slice under the previous item's gather: land it; the next item's
+            // slices are issued inside the gather loop below
+            land();
+            __syncthreads();
+        } else {
+            issue_stage(item);
         }
         // ---- parameters and taps of the first query while the value loads fly ----
         const float *__restrict__ refn = g.ref + (long)n * Lq * REFDIM;
@@ -233,26 +283,28 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
         if (have) raw = load_raw<REFDIM>(refn + (long)q * REFDIM, offn + q * off_stride, lgn + q * logit_stride);
         Taps tp;
         if (have) tp = make_taps<REFDIM>(raw, lv);
-        // ---- land the level in LDS: (y, x) of the pass's token advance by a constant step, no division ----
-        {
-            const int dy = (THREADS / 2) / W, dx = (THREADS / 2) - dy * W;
-            int y = t0 / W, x = t0 - y * W;
-            int idx = c0 * PL + (y + 1) * WB + x + 1;
-#pragma unroll
-            for (int u = 0; u < STAGE_PASSES; ++u) {
-                if (t0 + u * (THREADS / 2) < S) img[idx] = v[u];
-                x += dx;
-                idx += dy * WB + dx;
-                if (x >= W) { x -= W; idx += 2; }
-            }
+        if (!PREFETCH) {
+            land();
+            __syncthreads();
         }
-        __syncthreads();
 
-        // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters load meanwhile ----
-        while (have) {
+        // ---- gather: 16 corners x 2 chunks from LDS; the next query's parameters (and a slice of the next item's image)
+        // load meanwhile.  The trip count is the workgroup's, not the thread's, so that the slice index stays uniform ----
+        const int next_item = item + (int)gridDim.x;
+        const bool more = PREFETCH && next_item < g.nitems;
+        const float *src_next = nullptr;
+        if (more) {
+            const int nh = next_item & 7, nr = next_item >> 3, nn = nr / per, noct = (nr - nn * per) & 3;
+            src_next = g.value + nn * g.ly.value_frame + nh * g.ly.value_head + noct * g.ly.value_oct + t0 * vs_token + c0 * vs_chunk;
+        }
+        int slice = 0;
+        const int iters = (qend - qbeg + THREADS - 1) / THREADS;
+        for (int it = 0; it < iters; ++it) {
             const int qn = q + THREADS;
             const bool hn = qn < qend;
             if (hn) raw = load_raw<REFDIM>(refn + (long)qn * REFDIM, offn + qn * off_stride, lgn + qn * logit_stride);
+            if (more && slice < NSL) stage_slice(slice++, src_next);
+            if (!have) continue;                                  // (only in a workgroup's last iteration)
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 #if defined(DFX_LEVEL_ABLATE) && DFX_LEVEL_ABLATE == 3
             // timing ablation (results are wrong): no gather - the taps are computed and kept alive, nothing is read from LDS
@@ -298,6 +350,8 @@ __global__ __launch_bounds__(THREADS) void msda_fused_level(const LevelArgs g)
             q = qn;
             have = hn;
         }
+        if (more)
+            for (; slice < NSL; ++slice) stage_slice(slice, src_next);      // (few queries per item: the rest of the image now)
         __syncthreads();                            // every gather of this item is done before the next level lands
     }
 }
@@ -314,7 +368,7 @@ inline long plane_tokens(int H, int W)
 extern "C" int dfx_msda_fused_level_fits(int H, int W)
 {
     if (H <= 0 || W <= 0) return 0;
-    return 2 * plane_tokens(H, W) * 16 <= LDS_CAP && (long)H * W * 2 <= (long)STAGE_PASSES * THREADS;
+    return 2 * plane_tokens(H, W) * 16 <= LDS_CAP && (long)H * W * 2 <= (long)STAGE_SLOTS;
 }
 
 extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float *ref, int ref_dim, const float *off,
@@ -338,9 +392,14 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
         return dfx::fail(DFX_EINVAL, "msda level: a %d x %d level does not fit the 160 KB LDS image; "
                                      "use dfx_msda_fused_forward_f32", H, W);
     if ((long)N * Lq >= (1L << 28)) return dfx::fail(DFX_ERANGE, "msda level: too many queries");
+    // DFX_LEVEL_VARIANT=1 selects the round-4 variant - 512 threads, the next item's level prefetched into registers under the
+    // gather (see the kernel) - for A/B runs: measured 5-8 % SLOWER than the 1024-thread stage-then-gather schedule
+    // (profiles/r04_level_variant.txt), which stays the default
+    const bool pf = dfx::tuning().level_variant_set && dfx::tuning().level_variant == 1;
+    const int threads = pf ? 512 : 1024;
     // enough workgroups for the 256 CUs: split the queries of a frame when there are few frames
     int qsplit = 1;
-    while ((long)N * 32 * qsplit < 256 && qsplit < 8 && Lq / (qsplit * 2) >= THREADS / 2) qsplit *= 2;
+    while ((long)N * 32 * qsplit < 256 && qsplit < 8 && Lq / (qsplit * 2) >= 512) qsplit *= 2;
     const long blocks = (long)N * 32 * qsplit;
     if (blocks >= (1L << 31)) return dfx::fail(DFX_ERANGE, "msda level: grid too large");
     const int PL = (int)plane_tokens(H, W);
@@ -354,11 +413,11 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
     std::lock_guard<std::mutex> raise_lock(raise_mu);
     bool &raised = raised_on[dev & 63];
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_level<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fused_level<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess)
-            return dfx::fail(DFX_ELAUNCH, "msda level: cannot raise the dynamic LDS limit");
+        const void *fns[4] = {reinterpret_cast<const void *>(&msda_fused_level<2, 512, true>), reinterpret_cast<const void *>(&msda_fused_level<4, 512, true>),
+                              reinterpret_cast<const void *>(&msda_fused_level<2, 1024, false>), reinterpret_cast<const void *>(&msda_fused_level<4, 1024, false>)};
+        for (const void *fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess)
+                return dfx::fail(DFX_ELAUNCH, "msda level: cannot raise the dynamic LDS limit");
         raised = true;
     }
     const int S = H * W;
@@ -373,9 +432,12 @@ extern "C" int dfx_msda_fused_level_forward_f32(const float *value, const float 
     const long grid = (blocks < ncu || dfx::tuning().level_not_persistent) ? blocks : ncu;
     // algorithmic bytes of this launch: value + (offsets, logits) + out, fp32
     const long bytes = 4L * ((long)N * S * 256 + 3L * N * Lq * 8 * 4 + (long)N * Lq * 256);
-    if (ref_dim == 2)
-        dfx::launch_timed(bytes, Lq, S, msda_fused_level<2>, dim3((unsigned)grid), dim3(THREADS), lds, st, g);
-    else
-        dfx::launch_timed(bytes, Lq, S, msda_fused_level<4>, dim3((unsigned)grid), dim3(THREADS), lds, st, g);
+    if (pf) {
+        if (ref_dim == 2) dfx::launch_timed(bytes, Lq, S, msda_fused_level<2, 512, true>, dim3((unsigned)grid), dim3(threads), lds, st, g);
+        else dfx::launch_timed(bytes, Lq, S, msda_fused_level<4, 512, true>, dim3((unsigned)grid), dim3(threads), lds, st, g);
+    } else {
+        if (ref_dim == 2) dfx::launch_timed(bytes, Lq, S, msda_fused_level<2, 1024, false>, dim3((unsigned)grid), dim3(threads), lds, st, g);
+        else dfx::launch_timed(bytes, Lq, S, msda_fused_level<4, 1024, false>, dim3((unsigned)grid), dim3(threads), lds, st, g);
+    }
     return dfx::check_launch("msda_fused_level");
 }

@@ -341,6 +341,20 @@ def test_level_kernel_matches_oracle(msda, oracle, H, W, N, Lq, ref_dim, spread,
     assert torch.equal(_run_level_blocked(value, qproj, ref, H, W), got)
 
 
+@pytest.mark.parametrize("H,W,N,Lq,ref_dim,spread", [(50, 84, 8, 4200, 2, 3.0), (50, 84, 33, 4200, 2, 2.0), (50, 84, 1, 4200, 2, 30.0),
+                                                     (13, 21, 3, 273, 4, 4.0), (55, 86, 1, 2000, 2, 4.0)])
+def test_level_kernel_prefetch_variant(msda, oracle, dfx_env, H, W, N, Lq, ref_dim, spread):
+    """DFX_LEVEL_VARIANT=1 (csrc/msda_level.hip: 512-thread workgroups, the next item's level prefetched into registers slice by
+    slice under the gather; measured slower, profiles/r04_level_variant.txt, kept for A/B runs): the same bits as the default
+    schedule - per query the arithmetic is the same - also when a workgroup walks several items (N = 33: 1056 items on 256 CUs)."""
+    value, qproj, ref = _level_case(H * 17 + W + N, H, W, N, Lq, ref_dim, spread, Lq == H * W)
+    want = _run_level_blocked(value, qproj, ref, H, W)
+    dfx_env("DFX_LEVEL_VARIANT", "1")
+    got = _run_level_blocked(value, qproj, ref, H, W)
+    dfx_env("DFX_LEVEL_VARIANT", None)
+    assert torch.equal(got, want)
+
+
 def test_level_kernel_edges(msda, oracle):
     """Samples exactly on the skip-rule bounds (h_im = -1, H-1, H; w_im likewise), NaN / inf offsets and
     -inf logits: the same answer as the oracle (a dropped sample contributes 0)."""
