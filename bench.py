@@ -319,13 +319,17 @@ def main():
             del clip
         many = torch.cat(block, 0)
         del block
-        wide = ClipRunner(model, micro_batch=min(a.micro_batch, world * per_rank), overlap=bool(a.overlap))
-        for _ in range(max(1, a.warmup)):
-            wide(many, clips=world)
+        # the same clip pipeline as the one-GPU run (two eager lanes: every rank runs 32 frames per step here) when the block
+        # goes through in one pass; one call per step otherwise
+        wide = ClipRunner(model, micro_batch=min(a.micro_batch, world * per_rank), overlap=bool(a.overlap), lanes=2)
+        piped = pipelined and min(a.micro_batch, world * per_rank) >= world * per_rank
+        wide_step = (lambda: wide.submit(many, clips=world)) if piped else (lambda: wide(many, clips=world))
+        for _ in range(max(2, a.warmup)):
+            wide_step()
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.steps):
-            wide(many, clips=world)
+            wide_step()
         barrier()
         dt_stream = time.perf_counter() - t1
 
