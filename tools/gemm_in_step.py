@@ -26,6 +26,8 @@ model = build(dev, F_ - 1)
 runner = ClipRunner(model, micro_batch=F_)
 x = torch.randn(F_, 4, 800, 1333, device=dev)
 calls = []
+EACH = os.environ.get("EACH")          # "M,N,K": every launch of that conv1x1 shape on its own line, with the operands' addresses
+where = []
 _linear, _conv1x1, _pair = ops.linear, ops.conv1x1, ops.conv1x1_pair
 
 
@@ -49,7 +51,10 @@ def conv1x1(x, weight, bias=None, residual=None, relu=False, stride=1):
     h, w = (h + stride - 1) // stride, (w + stride - 1) // stride
     calls.append(("conv1x1", weight.shape[0], n * h * w, ci, ("+res" if residual is not None else "") + ("+relu" if relu else "")
                   + (f" /{stride}" if stride > 1 else "")))
-    return _conv1x1(x, weight, bias, residual, relu, stride)
+    out = _conv1x1(x, weight, bias, residual, relu, stride)
+    if EACH:
+        where.append((len(calls) - 1, x.data_ptr(), 0 if residual is None else residual.data_ptr(), out.data_ptr(), x.stride(), tuple(out.stride())))
+    return out
 
 
 def conv1x1_pair(x1, x2, weight, bias=None, relu=False):
@@ -70,7 +75,7 @@ with torch.no_grad():
 if len(rec) != len(calls):
     print(f"warning: {len(rec)} stamped launches for {len(calls)} wrapped calls (split-K / row ranges launch more than one)")
 rows = collections.OrderedDict()
-i = 0
+i = i_call = 0
 for c in calls:
     if i >= len(rec):
         break
@@ -80,6 +85,11 @@ for c in calls:
     while abs(work - flops) > 0.01 * flops and i < len(rec) and rec[i][1] != flops and work < flops:   # row ranges: sum the pieces
         sec, work = sec + rec[i][0], work + rec[i][1]
         i += 1
+    if EACH and c[0] == "conv1x1" and ",".join(str(v) for v in c[1:4]) == EACH:
+        w = next((v for v in where if v[0] == i_call), None)
+        print(f"  call {i_call:4d} {c[4]:12s} {sec * 1e6:8.1f} us  {work / sec / 1e12:6.1f} TFLOP/s" + ("" if w is None else
+              f"  x {w[1]:#x} r {w[2]:#x} y {w[3]:#x}  x.stride {w[4]} y.stride {w[5]}"))
+    i_call += 1
     r = rows.setdefault(c + (tb,), [0, 0.0, 0.0])
     r[0] += 1; r[1] += sec; r[2] += work
 tot = sum(r[1] for r in rows.values())
