@@ -193,6 +193,26 @@ def test_config_e_32_frame_clip_800x1333():
     assert rep["postprocess_box_idx"]["of"] == T * 100 and rep["temporal_topk_ordered"][0]["of"] == T * 2480
 
 
+@pytest.mark.parametrize("H,W", [(750, 1333), (800, 1067), (800, 1201)])
+@pytest.mark.timeout(900)
+def test_config_e_other_frame_shapes(H, W):
+    """The reference's resize rule (shorter side 800, longer side at most 1333: datasets/transforms_multi.py RandomResize
+    ([800], max_size=1333)) turns a 16:9 video into 750 x 1333 frames and a 4:3 one into 800 x 1067; 800 x 1201 has odd map
+    sizes on every level (76 x 51 at stride 16).  A 4-frame Late-Fusion clip of each through the CPU-oracle path and the
+    HIP path: other tile tails in every convolution, other token counts (47 x 84, 50 x 67, 50 x 76) in the level kernel."""
+    import bench
+    from tests import _config_e_check as chk
+    T = 4
+    clip = torch.randn(T, 4, H, W, generator=torch.Generator().manual_seed(H + W))
+    want, heads, _ = chk.cpu_reference_clip(bench.build, clip, min(16, os.cpu_count() or 1), timed_passes=1, warm_frames=0)
+    got = chk.hip_path_clip(bench.build, clip, heads)
+    rep = chk.compare(got, want, heads, H, W)
+    print(f"config E at {H} x {W}:", rep)
+    assert rep["max_abs_diff_pred_logits"] < 1e-3 and rep["max_abs_diff_pred_boxes"] < 1e-3
+    for r in [rep["postprocess_box_idx"], rep["postprocess_labels"]] + rep["temporal_topk_ordered"]:
+        assert r["share"] >= 0.7 and r["mismatches"] == 0, r
+
+
 def _ragged_pair():
     g = torch.Generator().manual_seed(77)
     return [torch.randn(4, 800, 1333, generator=g), torch.randn(4, 736, 1200, generator=g)]
