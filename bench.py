@@ -43,6 +43,8 @@ The JSON line also carries
                outputs, PostProcess labels / box indices and the ordered temporal top-k picks compared index by index
                outside a 2e-5 score tie margin, with the two ranking heads rescaled - on both sides - so that at least
                four ranks in five lie outside it: the oracle as checker at 800x1333).
+  literal_mode (N=1 only) SURVEY.md 8d's secondary figure: the detector's own forward over the 32 frames -> ONE output (frame 0
+               current), timed with the reference's protocol (benchmark.py:31-43: a device synchronize around every forward).
   e2e          frames/s x the per-frame algorithmic work of config E (tools/algorithmic_work.py) against the chip's peaks:
                `fp32_mfma_frac` counts the 3x3 stride-1 convolutions in DIRECT-form flops (what the reference computes),
                `fp32_mfma_frac_executed` in the flops the Winograd kernel executes (1/2.25 of them).
@@ -117,6 +119,33 @@ def build(device, num_ref_frames):
     return model.to(device).eval()
 
 
+def literal_mode(model, clip, warm=5, iters=30):
+    """SURVEY.md 8d's secondary figure: the detector's own forward as the reference times it - the T = 1 + R frames of a clip
+    go in, frame 0 is the current frame, ONE output comes back (deformable_detr_multi_plusplus.py:210 of the reference) -
+    with the reference's protocol (benchmark.py:31-43: warm-up, then a device synchronize around every forward, perf_counter).
+    Not the headline: in all-current mode every frame of the clip gets an output.  -> dictionary for the JSON line"""
+    from util.misc_multi import NestedTensor
+    samples = NestedTensor(clip, torch.zeros(clip.shape[0], clip.shape[2], clip.shape[3], dtype=torch.bool, device=clip.device))
+    times = []
+    with torch.no_grad():
+        for i in range(warm + iters):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = model(samples)
+            torch.cuda.synchronize()
+            if i >= warm:
+                times.append(time.perf_counter() - t0)
+    assert out["pred_logits"].shape[0] == 1 and bool(torch.isfinite(out["pred_logits"]).all())
+    times.sort()
+    mean = sum(times) / len(times)
+    T = clip.shape[0]
+    return {"clips_per_s": round(1.0 / mean, 3), "input_frames_per_s": round(T / mean, 2), "ms_per_forward_mean": round(mean * 1e3, 3),
+            "ms_per_forward_p50": round(times[len(times) // 2] * 1e3, 3), "iterations": iters, "warmup": warm,
+            "note": f"one forward of the detector over {T} frames -> 1 output (frame 0 current, R = {T - 1}), a device synchronize "
+                    "around every forward; the spatial stage of all frames + ONE temporal stage - the number comparable to timing "
+                    "the reference's forward, not the headline"}
+
+
 def cpu_baseline(height, width, threads, frames=32, warm_frames=2, passes=3):
     """The same host code on CPU tensors, the oracle as the MSDA / RoIAlign operator: clip 0 of the GPU workload
     (``frames`` frames, seed 42, R = frames - 1), ``passes`` timed passes after a ``warm_frames``-frame warm-up pass
@@ -174,6 +203,7 @@ def main():
                     help="frames per pass through the spatial stage (capped at the frames of the rank); larger "
                          "is faster up to the whole block: 8 -> 143.3, 16 -> 131.6, 32 -> 127.3 ms per 32-frame clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal", action="store_true", help="skip the secondary literal-mode figure (one output per clip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--overlap", type=int, default=1,
                     help="two-stream schedule inside a rank: backbones of micro-batch i+1 beside the transformer "
@@ -443,6 +473,8 @@ def main():
                 "clips_per_step": world, "frames_per_gpu": world * per_rank, "scaling": "weak",
                 "note": "same run, after the timed region: N clips per step, every rank runs its T/N frames of each (throughput mode of a "
                         "stream of clips); NOT the headline - BASELINE.json's configuration is one clip sharded over the GPUs"}
+        if world == 1 and clips == 1 and not a.no_literal:
+            line["literal_mode"] = literal_mode(model, mine)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, min(a.cpu_threads, os.cpu_count() or 1))
         print(json.dumps(line), flush=True)

@@ -308,3 +308,26 @@ def test_rccl_call_path_with_one_rank():
     env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=550, env=env)
     assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("H,W", [(64, 96), (800, 1333)])
+def test_literal_forward_is_frame_0_of_the_all_current_clip(H, W):
+    """The two modes of SURVEY.md 8d on one clip: the detector's own forward (T frames in, frame 0 current, the others its
+    references in clip order, ONE output: bench.py's secondary `literal_mode` figure) is what all-current mode - the headline -
+    emits for frame 0.  Both run the HIP path; the rows per GEMM launch differ (micro-batching), hence a tolerance."""
+    import bench
+    from models.clip_inference import ClipRunner
+    from util.misc_multi import NestedTensor
+    T = 4
+    dev = torch.device("cuda", 0)
+    model = bench.build(dev, T - 1)
+    clip = torch.randn(T, 4, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+    with torch.no_grad():
+        one = model(NestedTensor(clip, torch.zeros(T, H, W, dtype=torch.bool, device=dev)))
+    every = ClipRunner(model, micro_batch=T)(clip)
+    assert one["pred_logits"].shape[0] == 1 and every["pred_logits"].shape[0] == T
+    assert (one["pred_logits"][0] - every["pred_logits"][0]).abs().max().item() < 2e-5
+    assert (one["pred_boxes"][0] - every["pred_boxes"][0]).abs().max().item() < 2e-5
+    rep = bench.literal_mode(model, clip, warm=1, iters=2)
+    assert rep["iterations"] == 2 and rep["input_frames_per_s"] == pytest.approx(T * rep["clips_per_s"], rel=1e-2)
