@@ -287,6 +287,13 @@ class ClipRunner:
                                             clips=clips)
                 done = torch.cuda.Event(enable_timing=True)
                 done.record(s_tail)
+            # the outputs were allocated on the tail stream and are consumed on the caller's (after ``done``): tell the caching
+            # allocator, so that a block the caller frees is not handed out on the tail stream while the caller's kernels still read it
+            cur = torch.cuda.current_stream(dev)
+            for v in out.values():
+                for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
         finally:
             self.overlap = saved_overlap
         inflight.append((frames, staged, local, out, done))           # cross-stream tensors stay referenced until done
@@ -342,6 +349,10 @@ class ClipRunner:
                 out = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o.items()}
                 done = torch.cuda.Event(enable_timing=True)
                 done.record(stream)
+            for v in out.values():                                        # (as in ``submit``: consumed on the caller's stream)
+                for t in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
         finally:
             self.overlap = saved_overlap
         hold = self.__dict__.setdefault("_ginflight", {}).setdefault(skey, [])
