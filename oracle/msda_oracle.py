@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdfx_oracle.so")
+_SO = os.environ.get("DFX_ORACLE_LIBRARY") or os.path.join(_HERE, "libdfx_oracle.so")      # (override: a sanitizer build, tools/oracle_sanitize.sh)
 _lib = None
 
 
