@@ -264,8 +264,8 @@ extern "C" int dfx_conv2d_tile_f32(const float *x, const float *wp, const float 
     g.strideX = x_image_stride > 0 ? x_image_stride : (long)Ci * H * W;
     g.strideY = (long)Co * Ho * Wo;
     const long xel = (long)(N - 1) * g.strideX + (long)Ci * H * W;
-    if (xel * 4 >= (1L << 32) - 8 || (long)Co * Ho * Wo >= (1L << 31))
-        return dfx::fail(DFX_ERANGE, "conv2d_tile: the input batch exceeds 4 GiB (split the batch)");
+    if (xel * 4 >= (1L << 32) - 8 || (long)Co * Ho * Wo * 4 >= (1L << 32))      // (32-bit byte offsets inside the batch / one output image)
+        return dfx::fail(DFX_ERANGE, "conv2d_tile: the input batch or one output image exceeds 4 GiB (split the batch)");
     g.xbytes = (unsigned)(xel * 4);
     g.TY = (Ho + kTH - 1) / kTH;
     g.TX = (Wo + kTW - 1) / kTW;
