@@ -62,6 +62,7 @@ class ClipRunner:
         self.lanes = max(1, int(lanes))
         self.graph = bool(graph)
         self._graph_slots = {}
+        self._lane_carried_collectives = set()
         self._next_lane = 0
         self._lane_warm = set()
         self.micro_batch = micro_batch
@@ -325,7 +326,7 @@ class ClipRunner:
         saved_overlap, self.overlap = self.overlap, False
         try:
             if slot is None:
-                slot = self._capture_slot(frames, clips, first, sharded, stream, cur)
+                slot = self._capture_slot(frames, clips, first, sharded, stream, cur, skey in self._lane_carried_collectives)
                 self._graph_slots[key] = slot
             if slot is False:                                             # capture failed once (reported then): eager route
                 self.overlap = saved_overlap
@@ -341,6 +342,7 @@ class ClipRunner:
                 slot["g1"].replay()
                 if sharded:
                     ar, al = self.exchange(slot["local"]["ref"], slot["local"]["logits"], clips)
+                    self._lane_carried_collectives.add(skey)
                     slot["ref"].copy_(ar)
                     slot["logits"].copy_(al)
                     slot["g2"].replay()
@@ -362,22 +364,54 @@ class ClipRunner:
         return out, done
 
 
-    def _capture_slot(self, frames, clips, first, sharded, stream, cur):
+    def _pools_stand_in(self, ref, logits, clips):
+        """Tensors with the shapes (and clip-major order) of ``exchange``'s results, WITHOUT a collective: the rank's own rows
+        repeated.  For the eager passes that precede a capture."""
+        if "exchange" in self.__dict__:                       # (an instance-level stand-in that launches no collective either)
+            return self.exchange(ref, logits, clips)
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            return ref, logits
+        F_ = ref.shape[0] // clips
+
+        def rep(t):
+            return t.view(clips, F_, *t.shape[1:]).repeat(1, world, 1, 1).reshape(world * t.shape[0], *t.shape[1:])
+        return rep(ref), rep(logits)
+
+    def _capture_slot(self, frames, clips, first, sharded, stream, cur, lane_carried_collectives=False):
         """Graphs of one (lane, input shape): eager passes on the lane's stream first - every table built once (self._cached,
         util/memo.py), every kernel's one-time set-up done: a capture must not meet a blocking copy - then the capture(s), into
         one memory pool.  Other threads (the collective backend's watchdog) may call the runtime meanwhile: thread-local
-        capture mode.  -> the slot, or False when the capture failed (said once on stderr; the caller runs eagerly)."""
+        capture mode.  -> the slot, or False when the capture failed (said once on stderr; the caller runs eagerly).
+
+        The eager passes launch NO collective (``_pools_stand_in`` gives the temporal stage pools of the right shape; the
+        communicator is set up by one tiny exchange on the caller's stream).  torch.distributed's NCCL backend records a
+        completion event per collective on the stream it runs on (the lane's, for the blocking all-gather of ``exchange``) and
+        its watchdog thread polls that event until it has seen the collective finish - up to ~100 ms later; the HIP runtime
+        refuses the query of an event whose stream is capturing (hipErrorCapturedEvent: the capture is lost and the watchdog
+        takes the process down - one run in five of the one-rank RCCL test while the eager passes still ran the exchange).  So a
+        lane's stream has carried no collective when it captures.  A lane that captures a SECOND input shape has carried those
+        of its replays: the device is drained and the watchdog given time to retire them.
+        (Measured and dropped: the captures, or the eager passes, on a further stream shared by the lanes - the lanes' graphs then
+        partly serialise, 13.0 instead of 11.5 ms per 4-frame step; the exchange of a replay on a stream beside the lane: 12.6.)"""
         import sys
+        import time as _time
         slot, err = None, None
         try:
+            if sharded and not getattr(self, "_communicator_ready", False) and "exchange" not in self.__dict__:
+                tiny = torch.zeros((clips, 1, 1), dtype=frames.dtype, device=frames.device)
+                self.exchange(tiny, tiny, clips)               # (on the caller's stream, which is never captured here)
+                self._communicator_ready = True
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):
-                for _ in range(2):              # (every collective of the set-up happens here, before anything can fail)
+                for _ in range(2):
                     local = self._tail_block(self._encode_block(frames))
-                    ar, al = self.exchange(local["ref"], local["logits"], clips)
+                    ar, al = self._pools_stand_in(local["ref"], local["logits"], clips)
                     self.temporal_forward(local, ar, al, first_frame=first, clips=clips)
                 pools = (ar.clone(), al.clone()) if sharded else None        # static buffers of the gathered pools
-            stream.synchronize()
+            torch.cuda.synchronize(frames.device)
+            if lane_carried_collectives:
+                _time.sleep(0.5)
             slot = {"in": frames.clone()}
             slot["g1"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(slot["g1"], stream=stream, capture_error_mode="thread_local"):

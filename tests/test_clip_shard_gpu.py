@@ -307,7 +307,8 @@ def test_rccl_call_path_with_one_rank():
     import subprocess
     env = dict(os.environ, DFX_PKG=PKG, DFX_ROOT=ROOT, DFX_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, timeout=550, env=env)
-    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+    said = [ln for ln in out.stderr.splitlines() if any(w in ln for w in ("what()", "xception", "rror", "terminate"))][:12]
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, (out.returncode, out.stdout[-300:], said, out.stderr[-1500:])
 
 
 @pytest.mark.timeout(600)
