@@ -64,6 +64,12 @@ for _p in (PKG, ROOT):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The clip pipeline uses
+# two streams per eager lane / one per graph lane beside the default stream: with 4 queues two of the five streams of the
+# one-GPU default share a queue and partly serialise (tools/hw_queues_ab.sh, profiles/r04_hw_queues.txt: 391.6 -> 395.8 frames/s
+# with 8 queues; 4 frames per rank: 11.45 ms on 3 graph lanes -> 11.13 on 4).  Read when the runtime initialises: set first.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -216,7 +222,7 @@ def main():
                          "single-stream step)")
     ap.add_argument("--lanes", type=int, default=0,
                     help="independent stream pairs the clip pipeline deals consecutive steps to (ClipRunner(lanes=...): each lane "
-                         "keeps two clips in flight).  0 = 2 lanes for every N - one schedule over the scaling curve "
+                         "keeps two clips in flight).  0 = 2 eager lanes, or 4 HIP-graph lanes (3 with fewer than 8 hardware queues) "
                          "(tools/rank_step.py, profiles/r04_rank_step.txt: 4 frames per step 12.8 -> 11.6 ms, 8 frames 25.2 -> 21.7, "
                          "16 frames 43.2 -> 42.4, 32 frames 82.5 -> 81.8 ms with two lanes; three add nothing)")
     ap.add_argument("--graph", type=int, default=-1,
@@ -274,7 +280,8 @@ def main():
     # graphs by default whenever the clip is sharded (several ranks share one host: 85-88 % of an eager step is Python launch
     # time at 4-16 frames per rank, profiles/r04_rank_step.txt) or the step is short; one GPU with 32 frames stays eager (1 % ahead)
     use_graph = bool(a.graph) if a.graph >= 0 else ((world > 1 or rank_frames <= 4) and a.pipeline >= 1)
-    lanes = a.lanes if a.lanes > 0 else (3 if use_graph else 2)
+    hw_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    lanes = a.lanes if a.lanes > 0 else ((4 if hw_queues >= 8 else 3) if use_graph else 2)
     runner = ClipRunner(model, micro_batch=min(a.micro_batch, rank_frames), overlap=bool(a.overlap), lanes=lanes, graph=use_graph)
     n_micro = -(-rank_frames // min(a.micro_batch, rank_frames))
     overlapped = bool(a.overlap) and n_micro >= ClipRunner.MIN_OVERLAP_BATCHES
@@ -456,7 +463,7 @@ def main():
                        "micro_batch": min(a.micro_batch, rank_frames),
                        "parallelism": f"every clip frame-sharded x{world} ({per_rank} frames/GPU), {clips} clip(s) per step, "
                                       f"1 all-gather of the reference query sets per step",
-                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined, "pipeline_lanes": lanes if pipelined else 0,
+                       "two_stream_overlap": overlapped, "clip_pipeline": pipelined, "pipeline_lanes": lanes if pipelined else 0, "hip_hw_queues": hw_queues,
                        "hip_graphs": use_graph and pipelined and bool(runner._graph_slots) and all(v is not False for v in runner._graph_slots.values())},
             "roofline": roof,
             "roofline_kernels": kernels,

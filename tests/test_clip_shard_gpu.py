@@ -223,10 +223,13 @@ def test_bench_py_two_ranks_gloo_rehearsal(tmp_path, clips_per_step, pipeline, l
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["rccl"] == {"backend": "gloo", "world": 2}
     assert line["config"]["frames_per_gpu_per_clip"] == 2 and line["roofline"]["bound"] == "mfma"
-    # 2 frames per rank and step (<= 4): the pipelined steps are HIP-graph replays on 3 lanes, the exchange between the two
-    # graphs of a step goes over the process group eagerly; the N-clips-per-step mode (4 frames per rank) too
+    # 2 frames per rank and step (<= 4): the pipelined steps are HIP-graph replays on 4 lanes (bench.py asks the HIP runtime
+    # for 8 hardware queues), the exchange between the two graphs of a step goes over the process group eagerly; the
+    # N-clips-per-step mode (4 frames per rank) too
     graphs = pipeline >= 1
-    assert line["config"]["clip_pipeline"] == (pipeline >= 1) and line["config"]["pipeline_lanes"] == (3 if pipeline else 0)
+    assert line["config"]["hip_hw_queues"] == int(os.environ.get("GPU_MAX_HW_QUEUES", "8"))
+    assert line["config"]["clip_pipeline"] == (pipeline >= 1)
+    assert line["config"]["pipeline_lanes"] == ((4 if line["config"]["hip_hw_queues"] >= 8 else 3) if pipeline else 0)
     assert line["config"]["hip_graphs"] == graphs
     assert line["ms_per_step_p50"] > 0
     if clips_per_step == 0:
