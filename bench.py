@@ -229,7 +229,7 @@ def main():
                     help="1: the clip pipeline replays every rank step as HIP graphs (ClipRunner(graph=True): spatial stage + "
                          "query/RoI fusion, eager exchange, temporal stage) instead of launching ~1500 kernels from Python - same "
                          "kernels, bit-equal outputs, host time per step from 10.8 ms to 0.3 ms at 4 frames per rank, where the "
-                         "eager host is 88 %% busy; a lane is then one stream (3 lanes).  -1 (default) = on for every N > 1 (ranks share "
+                         "eager host is 88 %% busy; a lane is then one stream (4 lanes).  -1 (default) = on for every N > 1 (ranks share "
                          "a host; 12.3 -> 11.6 ms per 4-frame step, level at 8 and 16 frames: profiles/r04_rank_step.txt), off for "
                          "one GPU with 32 frames per step (eager 1 %% ahead)")
     ap.add_argument("--deterministic", type=int, default=0,

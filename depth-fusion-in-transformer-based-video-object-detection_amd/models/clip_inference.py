@@ -55,7 +55,8 @@ class ClipRunner:
         graph: ``submit`` replays the rank step as HIP graphs (one per lane and input shape: the spatial stage + query/RoI
         fusion, then - after the eager exchange when the clip is sharded - the temporal stage) instead of launching its ~1500
         kernels from Python: the same kernels and bit-equal outputs, the host side of a 4-frame step drops from ~9 ms to
-        well under 1 ms (8 ranks share one host).  A lane is then ONE stream with one clip in flight; use 3-4 lanes.  Masked
+        well under 1 ms (8 ranks share one host).  A lane is then ONE stream with one clip in flight; use 3 lanes, or 4 with
+        GPU_MAX_HW_QUEUES=8 (the HIP runtime maps a process's streams onto 4 hardware queues by default: INTEGRATION.md).  Masked
         (padded) clips take the eager route."""
         self.model = model
         self.gather_on_one_rank = gather_on_one_rank
