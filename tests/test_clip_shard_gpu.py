@@ -288,11 +288,21 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))  # RCCL
 runner = ClipRunner(model, micro_batch=4, gather_on_one_rank=True)   # run the collective although world == 1
 got = runner(clip)                                                   # all_gather_into_tensor on the current stream
 outs = [runner.submit(clip) for _ in range(3)]                       # ... and on the side stream of the clip pipeline
-grunner = ClipRunner(model, micro_batch=4, gather_on_one_rank=True, lanes=3, graph=True)
+calls = []
+class Spy(ClipRunner):                                               # which stream every collective runs on, and what was captured by then
+    def exchange(self, ref, logits, clips=1):
+        calls.append((torch.cuda.current_stream().stream_id, {k[0] for k in self._graph_slots}))
+        return super().exchange(ref, logits, clips)
+grunner = Spy(model, micro_batch=4, gather_on_one_rank=True, lanes=3, graph=True)
 outs += [grunner.submit(clip) for _ in range(7)]                     # ... and between the two HIP graphs of a step, three lanes
 torch.cuda.synchronize()
 dist.barrier()
 assert len(grunner._graph_slots) == 3 and all(isinstance(v, dict) and "g2" in v for v in grunner._graph_slots.values()), "captures fell back"
+# the watchdog polls a collective's completion event; HIP refuses that while the event's stream captures: a lane's stream
+# carries no collective before the lane has captured (the communicator is set up on the caller's stream)
+lanes = {s.stream_id: k for k, s in grunner._streams.items() if isinstance(k, tuple) and isinstance(k[0], str) and isinstance(k[1], int)}
+assert len(lanes) == 3 and sum(sid in lanes for sid, _ in calls) == 7 and any(sid not in lanes for sid, _ in calls)
+assert all(lanes[sid] in captured for sid, captured in calls if sid in lanes), "a collective ran on a lane's stream before the lane captured"
 for o in [got] + [o for o, _ in outs]:
     for k in ("pred_logits", "pred_boxes"):
         assert torch.equal(o[k], want[k]), k
