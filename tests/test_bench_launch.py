@@ -36,3 +36,15 @@ def test_mismatched_world_size_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=120, env=env)
     assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=4" in out.stderr
+
+
+def test_bench_asks_for_eight_hardware_queues_unless_told_otherwise():
+    """bench.py sets GPU_MAX_HW_QUEUES=8 before torch is imported (the HIP runtime reads it when it initialises; two eager
+    pipeline lanes are five streams, profiles/r04_hw_queues.txt) and leaves a value from the environment alone."""
+    code = "import os, bench; print('HWQ', os.environ['GPU_MAX_HW_QUEUES'])"
+    for preset, want in ((None, "8"), ("4", "4")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset is not None:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert out.returncode == 0 and f"HWQ {want}" in out.stdout, out.stderr[-1000:]
